@@ -1,0 +1,233 @@
+/*
+ * trajopt_amd.h - C ABI of the MI355X-native batched iLQR / Riccati engine.
+ *
+ * This is the drop-in boundary for the hot path of hanyas/trajopt: the pybind11/Armadillo module
+ * `trajopt.ilqr.core` (one function, /root/reference/trajopt/ilqr/src/util.cpp:83-188) plus the
+ * Python loops around it (/root/reference/trajopt/ilqr/ilqr.py:89-237,
+ * /root/reference/trajopt/riccati/riccati.py:100-126).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - All real data is IEEE double.  Matrices are column-major; time is the slowest per-problem axis,
+ *     exactly the reference's f_style arrays:  X(i, j, t) = X[i + rows*j + rows*cols*t]  (util.cpp:10,21).
+ *   - A batch of `nb_problems` independent problems is stored in one of two layouts:
+ *       TRAJOPT_LAYOUT_PROBLEM_MAJOR  X(p, i, j, t) = X[p*rows*cols*slices + i + rows*j + rows*cols*t]
+ *                                     (a stack of reference-layout problems; nb_problems == 1 IS the
+ *                                      reference layout)
+ *       TRAJOPT_LAYOUT_PROBLEM_MINOR  X(p, i, j, t) = X[(i + rows*j + rows*cols*t)*nb_problems + p]
+ *                                     (struct-of-arrays, problem index fastest: consecutive lanes read
+ *                                      consecutive addresses)
+ *     Per-problem scalars (lmbda, diverge, returns ...) are plain [nb_problems] vectors in both layouts.
+ *   - Pointers named *_host are host memory; every other data pointer is DEVICE memory of the current
+ *     HIP device.  `stream` is a hipStream_t passed as void* (NULL = the default stream).  Batched entry
+ *     points are asynchronous on `stream`, allocate nothing, and never synchronise.
+ *   - Return value: TRAJOPT_OK or a negative TRAJOPT_ERR_*.  A numerically failed problem (non-PD Quu)
+ *     is DATA (`diverge[p]`), never an error (util.cpp:145-148).
+ */
+#ifndef TRAJOPT_AMD_H
+#define TRAJOPT_AMD_H
+
+#include <stdint.h>
+#include "trajopt_env.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRAJOPT_ABI_VERSION 1
+
+#define TRAJOPT_OK 0
+#define TRAJOPT_ERR_BAD_ARG (-1)      /* null pointer, non-positive size, unknown enum            */
+#define TRAJOPT_ERR_UNSUPPORTED (-2)  /* shape outside what the kernels are built for             */
+#define TRAJOPT_ERR_HIP (-3)          /* a HIP runtime call failed; see trajopt_last_hip_error()  */
+#define TRAJOPT_ERR_NO_DEVICE (-4)    /* no usable GPU: there is no CPU fallback by design        */
+
+#define TRAJOPT_LAYOUT_PROBLEM_MAJOR 0
+#define TRAJOPT_LAYOUT_PROBLEM_MINOR 1
+
+#define TRAJOPT_MAX_ALPHAS 16
+
+int trajopt_abi_version(void);
+const char* trajopt_error_string(int code);
+const char* trajopt_last_hip_error(void);
+/* Number of visible HIP devices, or TRAJOPT_ERR_NO_DEVICE. */
+int trajopt_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Regularisation (lambda) schedule of iLQR.run, ilqr.py:166-167 (grow) and :207-208 (shrink).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct trajopt_lambda_schedule {
+    double min_lmbda;   /* ilqr.py:16  default 1e-6 */
+    double max_lmbda;   /* ilqr.py:17  default 1e6  */
+    double mult_lmbda;  /* ilqr.py:17  default 1.6  */
+} trajopt_lambda_schedule_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * A1.  Regularised Riccati / DDP backward pass.
+ * Replaces `core.backward_pass` (util.cpp:83-182); called from iLQR.backward_pass (ilqr.py:104-117).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Exact counterpart of the pybind11 entry (util.cpp:83-87,179-180): ONE problem, HOST arrays in the
+ * reference layout, scalar lmbda.  Outputs are caller-allocated:
+ *   Qxx(n,n,T) Qux(m,n,T) Quu(m,m,T) qx(n,T) qu(m,T) V(n,n,T+1) v(n,T+1) dV(2) K(m,n,T) kff(m,T).
+ * Slices the recursion never reaches after a divergence are written as zeros (the reference leaves
+ * them uninitialised).  *diverge receives the reference's `_diverge` (time index of the failing step,
+ * 0 when none - util.cpp:120,146); *failed (may be NULL) receives the unambiguous flag.
+ * Copies to the device, runs the same kernels as the batched entry, copies back, synchronises. */
+int trajopt_ilqr_backward_pass_host(const double* Cxx_host, const double* cx_host, const double* Cuu_host,
+                                    const double* cu_host, const double* Cxu_host, const double* A_host,
+                                    const double* B_host, double lmbda, int reg, int dm_state, int dm_act,
+                                    int nb_steps, double* Qxx_host, double* Qux_host, double* Quu_host,
+                                    double* qx_host, double* qu_host, double* V_host, double* v_host,
+                                    double* dV_host, double* K_host, double* kff_host, int* diverge,
+                                    int* failed);
+
+typedef struct trajopt_backward_io {
+    /* inputs (ilqr.py:112-114): cost arrays have nb_steps+1 slices, A/B have nb_steps */
+    const double* Cxx; const double* cx; const double* Cuu; const double* cu; const double* Cxu;
+    const double* A; const double* B;
+    /* per-problem regularisation, [nb_problems].  Read; written back when `retry` != 0. */
+    double* lmbda;
+    double* dlmbda;       /* [nb_problems]; only used (read+written) when retry != 0, else may be NULL */
+    /* optional outputs: a NULL pointer skips the store ("gains-only" when all seven are NULL) */
+    double* Qxx; double* Qux; double* Quu; double* qx; double* qu; double* V; double* v;
+    /* required outputs */
+    double* dV;           /* (2,) per problem */
+    double* K; double* kff;
+    int32_t* diverge;     /* [nb_problems]: -1 = every step passed the PD test, else the failing time index */
+    /* optional: uref (m, T) per problem; when non-NULL the kernel also returns
+     * g_norm[p] = mean_j max_t |kff_jt| / (|uref_jt| + 1)  (ilqr.py:176) */
+    const double* uref;
+    double* g_norm;       /* [nb_problems], may be NULL */
+    /* optional activity mask [nb_problems]: problems with active[p] == 0 are skipped entirely */
+    const int32_t* active;
+} trajopt_backward_io_t;
+
+/* Batched backward pass on device arrays.  reg: 1 = lmbda*I on Quu, 2 = lmbda*I on V' (util.cpp:135-143),
+ * anything else = no regularisation term (as the reference).  retry != 0 repeats a diverged problem
+ * inside the kernel with lmbda grown per ilqr.py:166-167 until it passes or lmbda > max_lmbda
+ * (ilqr.py:162-173); `sched` may be NULL when retry == 0. */
+int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg, int dm_state, int dm_act,
+                                       int nb_steps, int64_t nb_problems, int layout, int retry,
+                                       const trajopt_lambda_schedule_t* sched, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A9.  Time-varying LQR backward sweep with affine dynamics term c ("no-1/2" convention).
+ * Replaces the NumPy loop Riccati.backward_pass (riccati.py:100-126).  V = Qxx + Qux^T K uses the
+ * matrix product (the reference's elementwise `*` at :123 coincides with it only for dm_act == 1).
+ * Outputs: K(m,n,T) kff(m,T) V(n,n,T+1) v(n,T+1).  status[p] (may be NULL): 0 ok, t+1 if Quu was
+ * singular at step t (np.linalg.inv would raise).
+ * ---------------------------------------------------------------------------------------------- */
+int trajopt_riccati_backward_pass_host(const double* Cxx_host, const double* cx_host, const double* Cuu_host,
+                                       const double* cu_host, const double* Cxu_host, const double* A_host,
+                                       const double* B_host, const double* c_host, int dm_state, int dm_act,
+                                       int nb_steps, double* V_host, double* v_host, double* K_host,
+                                       double* kff_host, int* status);
+
+int trajopt_riccati_backward_pass_batched(const double* Cxx, const double* cx, const double* Cuu,
+                                          const double* cu, const double* Cxu, const double* A, const double* B,
+                                          const double* c, int dm_state, int dm_act, int nb_steps,
+                                          int64_t nb_problems, int layout, double* V, double* v, double* K,
+                                          double* kff, int32_t* status, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A8.  Env model evaluated on the device: xn = env.dynamics(x, u), c = env.cost(x, u, u_last, a)
+ * (e.g. cartpole.py:62-97,112-127).  x (n, N), u (m, N), PROBLEM_MINOR or MAJOR per `layout`.
+ * Either output may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int trajopt_env_step_batched(const trajopt_env_t* env, const double* x, const double* u, const double* u_last,
+                             const double* a, int64_t nb_problems, int layout, double* xn, double* cost,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A3.  Forward rollout under the affine law, for every (problem, alpha) pair:
+ *   u_t = clip(uref_t + alpha*kff_t + K_t (x_t - xref_t), +-umax); cost_t = env.cost(x_t, u_t, u_t, w_t);
+ *   x_{t+1} = env.dynamics(x_t, u_t); cost_T = env.cost(x_T, 0, 0, w_T)         (ilqr.py:89-102,
+ *   objects.py:137-139).
+ * x0 (n,) per problem.  alphas_host[nb_alphas] (<= TRAJOPT_MAX_ALPHAS).  weighting [nb_steps+1] device.
+ * Candidate outputs carry a leading alpha axis: state[a] (n, T+1), action[a] (m, T), cost[a] (T+1)
+ * per problem in `layout` (alpha slowest); any of the three may be NULL.
+ * ret[a*nb_problems + p] = sum_t cost;  finite[a*nb_problems + p] = all(state < 1e8) (ilqr.py:141).
+ * ---------------------------------------------------------------------------------------------- */
+int trajopt_ilqr_forward_pass_batched(const trajopt_env_t* env, int nb_steps, int64_t nb_problems, int layout,
+                                      const double* x0, const double* K, const double* kff, const double* xref,
+                                      const double* uref, const double* weighting, const double* alphas_host,
+                                      int nb_alphas, const int32_t* active, double* state, double* action,
+                                      double* cost, double* ret, int32_t* finite, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A4 + A5 (+A10).  Quadratisation along a reference trajectory.
+ *   A_t = d dynamics/dx, B_t = d dynamics/du at (xref_t, uref_t), t < T          (objects.py:114-117)
+ *   Cxx, cx, Cuu, cu, Cxu at (xref_t, [uref,0]_t, [uref,0]_{t-1}, w_t), t <= T   (objects.py:68-78)
+ * convention 0 = iLQR (no 1/2, no de-centring); 1 = Riccati (riccati/objects.py:54-65,102-108: Hessians
+ * halved, linear terms de-centred, affine residual c (n, T) also written; `c` must be non-NULL).
+ * Derivatives are exact (forward-mode dual numbers through clip -> RK4 -> clip, autograd's clip rule).
+ * ---------------------------------------------------------------------------------------------- */
+int trajopt_quadratize_batched(const trajopt_env_t* env, int nb_steps, int64_t nb_problems, int layout,
+                               int convention, const double* xref, const double* uref, const double* weighting,
+                               const int32_t* active, double* A, double* B, double* c, double* Cxx, double* cx,
+                               double* Cuu, double* cu, double* Cxu, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A6.  Batched iLQR driver: everything iLQR.run keeps per problem (ilqr.py:136-237), resident on the
+ * device, PROBLEM_MINOR layout.  The caller (PyTorch on the Python side) owns every buffer.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct trajopt_ilqr_options {
+    trajopt_lambda_schedule_t sched;
+    double tolfun;    /* ilqr.py:17 */
+    double tolgrad;   /* ilqr.py:18 */
+    double min_imp;   /* ilqr.py:18 */
+    int32_t reg;      /* ilqr.py:18 */
+    int32_t nb_alphas;
+    double alphas[TRAJOPT_MAX_ALPHAS];  /* ilqr.py:15 */
+    int32_t argmin_alpha;  /* 0 = reference's first-accept order (ilqr.py:187-202); 1 = lowest return among accepted */
+    int32_t keep_value;    /* 1 = also maintain vfunc/qfunc (V, v, Qxx, Qux, Quu, qx, qu) on accept    */
+} trajopt_ilqr_options_t;
+
+typedef struct trajopt_ilqr_workspace {
+    int32_t nb_steps; int32_t pad_;
+    int64_t nb_problems;
+    /* problem data */
+    const double* x0;         /* (n,)            */
+    const double* weighting;  /* [T+1], shared   */
+    /* accepted solution (ilqr.py:210-217) */
+    double* xref; double* uref;          /* (n,T+1), (m,T)          */
+    double* K; double* kff;              /* ctl: (m,n,T), (m,T)      */
+    double* V; double* v;                /* vfunc, only if keep_value */
+    double* Qxx; double* Qux; double* Quu; double* qx; double* qu;   /* qfunc, only if keep_value */
+    /* per-problem scalars, [nb_problems] */
+    double* last_return; double* lmbda; double* dlmbda; double* alpha;
+    int32_t* status;      /* 0 running, 1 tolgrad, 2 tolfun, 3 lmbda > max (ilqr.py:177,222,168/228)  */
+    int32_t* iters;       /* iterations executed                                                      */
+    int32_t* trace_len;   /* entries written to trace                                                 */
+    double* trace;        /* [trace_cap][nb_problems] accepted returns (ilqr.py:149,219)             */
+    int32_t trace_cap; int32_t pad2_;
+    /* scratch, all PROBLEM_MINOR */
+    double* A; double* B; double* Cxx; double* cx; double* Cuu; double* cu; double* Cxu;   /* quadratisation */
+    double* cand_K; double* cand_kff;    /* backward-pass candidate gains                             */
+    double* cand_V; double* cand_v; double* cand_Qxx; double* cand_Qux; double* cand_Quu; double* cand_qx;
+    double* cand_qu;                     /* only if keep_value                                        */
+    double* dV; double* g_norm;
+    int32_t* diverge; int32_t* active;
+    int32_t* sel;                        /* [nb_problems] index of the accepted alpha, -1 = none       */
+    double* cand_state; double* cand_action; double* cand_ret;   /* [nb_alphas] candidates            */
+    int32_t* cand_finite;
+} trajopt_ilqr_workspace_t;
+
+/* ilqr.py:139-149: initial rollout of ws->K / ws->kff over the alphas; first one with all(state < 1e8)
+ * becomes xref/uref/last_return and trace[0]. */
+int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
+                              const trajopt_ilqr_workspace_t* ws, void* stream);
+/* `nb_iter` iterations of ilqr.py:151-231 for every problem whose status is 0, without any host
+ * synchronisation: quadratise -> backward pass with in-kernel lambda retries -> gradient-norm stop ->
+ * rollout over all alphas -> first-accept selection -> accept/reject and lambda update. */
+int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
+                         const trajopt_ilqr_workspace_t* ws, int nb_iter, void* stream);
+
+/* Layout conversion helper (device to device): dst = src re-laid-out; rows*cols*slices elements/problem. */
+int trajopt_convert_layout(const double* src, double* dst, int64_t elems_per_problem, int64_t nb_problems,
+                           int src_layout, int dst_layout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAJOPT_AMD_H */

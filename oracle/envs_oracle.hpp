@@ -1,0 +1,261 @@
+// ORACLE - TEST INFRASTRUCTURE ONLY (see riccati_oracle.hpp for the rules).  PARITY UNPINNED.
+//
+// CPU restatement of the env layer the iLQR / Riccati hot path consumes (row A8 of SURVEY 8a):
+//   pendulum         /root/reference/trajopt/envs/pendulum/pendulum.py:58-76 (dynamics), :111-125 (cost)
+//   cartpole         /root/reference/trajopt/envs/cartpole/cartpole.py:62-97, :112-127
+//   double cartpole  /root/reference/trajopt/envs/double_cartpole/double_cartpole.py:61-155, :170-187
+//   LQR (affine LTI) /root/reference/trajopt/envs/lqr/lqr_v0.py:50-66, :89-94
+//   quadrotor        build-defined 12-state rigid body (NOT in the reference; SURVEY "Facts", C4)
+// and of the autograd derivatives the reference takes of them (objects.py:58-63,108-109): forward-mode
+// dual numbers here, which reproduce autograd's reverse-mode Jacobians to round-off.  autograd's
+// np.clip VJP is g * (ans != a_min) * (ans != a_max): derivative 0 when the output sits on a bound.
+#pragma once
+#include <cmath>
+#include "../include/trajopt_env.h"
+
+namespace oracle {
+
+template <int K>
+struct Dual {
+    double v;
+    double d[K > 0 ? K : 1];
+    Dual() : v(0) { for (int k = 0; k < K; ++k) d[k] = 0; }
+    Dual(double x) : v(x) { for (int k = 0; k < K; ++k) d[k] = 0; }
+};
+template <int K> Dual<K> operator+(const Dual<K>& a, const Dual<K>& b) { Dual<K> r; r.v = a.v + b.v; for (int k = 0; k < K; ++k) r.d[k] = a.d[k] + b.d[k]; return r; }
+template <int K> Dual<K> operator-(const Dual<K>& a, const Dual<K>& b) { Dual<K> r; r.v = a.v - b.v; for (int k = 0; k < K; ++k) r.d[k] = a.d[k] - b.d[k]; return r; }
+template <int K> Dual<K> operator-(const Dual<K>& a) { Dual<K> r; r.v = -a.v; for (int k = 0; k < K; ++k) r.d[k] = -a.d[k]; return r; }
+template <int K> Dual<K> operator*(const Dual<K>& a, const Dual<K>& b) { Dual<K> r; r.v = a.v * b.v; for (int k = 0; k < K; ++k) r.d[k] = a.d[k] * b.v + a.v * b.d[k]; return r; }
+template <int K> Dual<K> operator/(const Dual<K>& a, const Dual<K>& b) { Dual<K> r; r.v = a.v / b.v; for (int k = 0; k < K; ++k) r.d[k] = (a.d[k] - r.v * b.d[k]) / b.v; return r; }
+template <int K> Dual<K> operator+(const Dual<K>& a, double b) { Dual<K> r = a; r.v += b; return r; }
+template <int K> Dual<K> operator+(double b, const Dual<K>& a) { Dual<K> r = a; r.v += b; return r; }
+template <int K> Dual<K> operator-(const Dual<K>& a, double b) { Dual<K> r = a; r.v -= b; return r; }
+template <int K> Dual<K> operator-(double b, const Dual<K>& a) { Dual<K> r = -a; r.v += b; return r; }
+template <int K> Dual<K> operator*(const Dual<K>& a, double b) { Dual<K> r; r.v = a.v * b; for (int k = 0; k < K; ++k) r.d[k] = a.d[k] * b; return r; }
+template <int K> Dual<K> operator*(double b, const Dual<K>& a) { return a * b; }
+template <int K> Dual<K> operator/(const Dual<K>& a, double b) { Dual<K> r; r.v = a.v / b; for (int k = 0; k < K; ++k) r.d[k] = a.d[k] / b; return r; }
+template <int K> Dual<K> operator/(double b, const Dual<K>& a) { return Dual<K>(b) / a; }
+template <int K> Dual<K> sin(const Dual<K>& a) { Dual<K> r; r.v = std::sin(a.v); double c = std::cos(a.v); for (int k = 0; k < K; ++k) r.d[k] = c * a.d[k]; return r; }
+template <int K> Dual<K> cos(const Dual<K>& a) { Dual<K> r; r.v = std::cos(a.v); double s = -std::sin(a.v); for (int k = 0; k < K; ++k) r.d[k] = s * a.d[k]; return r; }
+template <int K> Dual<K> tan(const Dual<K>& a) { Dual<K> r; r.v = std::tan(a.v); double s = 1.0 + r.v * r.v; for (int k = 0; k < K; ++k) r.d[k] = s * a.d[k]; return r; }
+inline double val(double a) { return a; }
+template <int K> double val(const Dual<K>& a) { return a.v; }
+using std::sin; using std::cos; using std::tan;
+
+// np.clip(x, -lim, lim) and its autograd derivative mask.
+inline double clip(double x, double lim) { return std::fmin(std::fmax(x, -lim), lim); }
+template <int K> Dual<K> clip(const Dual<K>& x, double lim) {
+    Dual<K> r; r.v = clip(x.v, lim);
+    const double mask = (r.v != -lim && r.v != lim) ? 1.0 : 0.0;
+    for (int k = 0; k < K; ++k) r.d[k] = mask * x.d[k];
+    return r;
+}
+
+// ---- continuous-time vector fields ----------------------------------------------------------
+template <class X> void f_pendulum(const trajopt_env_t& e, const X* x, const X* u, X* dx) {
+    // pendulum.py:61-66
+    const double g = e.phys[0], m = e.phys[1], l = e.phys[2], k = e.phys[3];
+    X th = x[0], dth = x[1];
+    dx[0] = dth;
+    dx[1] = -3. * g / (2. * l) * sin(th + M_PI) + 3. / (m * l * l) * (u[0] - k * dth);
+}
+template <class X> void f_cartpole(const trajopt_env_t& e, const X* x, const X* u, X* dx) {
+    // cartpole.py:67-87
+    const double g = e.phys[0], Mc = e.phys[1], Mp = e.phys[2], l = e.phys[3], fr = e.phys[4];
+    const double Mt = Mc + Mp;
+    X th = x[1], dq = x[2], dth = x[3];
+    X sth = sin(th), cth = cos(th);
+    X num = g * sth + cth * (-(u[0] - fr * dq) - Mp * l * dth * dth * sth) / Mt;
+    X denom = l * ((4. / 3.) - Mp * cth * cth / Mt);
+    X ddth = num / denom;
+    X ddx = (u[0] + Mp * l * (dth * dth * sth - ddth * cth)) / Mt;
+    dx[0] = dq; dx[1] = dth; dx[2] = ddx; dx[3] = ddth;
+}
+template <class X> void f_double_cartpole(const trajopt_env_t& e, const X* x, const X* u, X* dx) {
+    // double_cartpole.py:71-145
+    const double g = e.phys[0], Mc = e.phys[1], Mp1 = e.phys[2], Mp2 = e.phys[3], L1 = e.phys[4], L2 = e.phys[5];
+    const double Mt = Mc + Mp1 + Mp2, l1 = L1 / 2., l2 = L2 / 2., J1 = Mp1 * L1 / 12., J2 = Mp2 * L2 / 12.;
+    X th1 = x[1], th2 = x[2], dq = x[3], dth1 = x[4], dth2 = x[5];
+    X s1 = sin(th1), c1 = cos(th1), s2 = sin(th2), c2 = cos(th2);
+    X sdth = sin(th1 - th2), cdth = cos(th1 - th2);
+    const double l1_mp1_mp2 = Mp1 * l1 + Mp2 * L2;
+    X l1_mp1_mp2_c1 = l1_mp1_mp2 * c1;
+    const double Mp2_l2 = Mp2 * l2;
+    X Mp2_l2_c2 = Mp2_l2 * c2;
+    const double l1_l2_Mp2 = L1 * l2 * Mp2;
+    X l1_l2_Mp2_cdth = l1_l2_Mp2 * cdth;
+    X Mm[3][3];
+    Mm[0][0] = X(Mt); Mm[0][1] = l1_mp1_mp2_c1; Mm[0][2] = Mp2_l2_c2;
+    Mm[1][0] = l1_mp1_mp2_c1; Mm[1][1] = X((l1 * l1) * Mp1 + (L1 * L1) * Mp2 + J1); Mm[1][2] = l1_l2_Mp2_cdth;
+    Mm[2][0] = Mp2_l2_c2; Mm[2][1] = l1_l2_Mp2_cdth; Mm[2][2] = X((l2 * l2) * Mp2 + J2);
+    X C12 = -l1_mp1_mp2 * dth1 * s1, C13 = -Mp2_l2 * dth2 * s2;
+    X C23 = l1_l2_Mp2 * dth2 * sdth, C32 = -l1_l2_Mp2 * dth1 * sdth;
+    X G2 = -(Mp1 * l1 + Mp2 * L1) * g * s1, G3 = -Mp2 * l2 * g * s2;
+    // rhs = action - C dx - G   (:139-143)
+    X rhs[3];
+    rhs[0] = u[0] - (C12 * dth1 + C13 * dth2);
+    rhs[1] = X(0.) - (C23 * dth2) - G2;
+    rhs[2] = X(0.) - (C32 * dth1) - G3;
+    // ddx = inv(M) rhs : Gaussian elimination with partial pivoting on the values
+    int piv[3] = {0, 1, 2};
+    for (int k = 0; k < 3; ++k) {
+        int p = k;
+        for (int i = k + 1; i < 3; ++i)
+            if (std::fabs(val(Mm[piv[i]][k])) > std::fabs(val(Mm[piv[p]][k]))) p = i;
+        int tmp = piv[k]; piv[k] = piv[p]; piv[p] = tmp;
+        for (int i = k + 1; i < 3; ++i) {
+            X fct = Mm[piv[i]][k] / Mm[piv[k]][k];
+            for (int j = k; j < 3; ++j) Mm[piv[i]][j] = Mm[piv[i]][j] - fct * Mm[piv[k]][j];
+            rhs[piv[i]] = rhs[piv[i]] - fct * rhs[piv[k]];
+        }
+    }
+    X dd[3];
+    for (int i = 2; i >= 0; --i) {
+        X s = rhs[piv[i]];
+        for (int j = i + 1; j < 3; ++j) s = s - Mm[piv[i]][j] * dd[j];
+        dd[i] = s / Mm[piv[i]][i];
+    }
+    dx[0] = dq; dx[1] = dth1; dx[2] = dth2; dx[3] = dd[0]; dx[4] = dd[1]; dx[5] = dd[2];
+}
+template <class X> void f_quadrotor(const trajopt_env_t& e, const X* x, const X* u, X* dx) {
+    // build-defined: x = [p(3), euler phi/theta/psi, v(3) world, body rates p q r], u = 4 rotor thrusts
+    const double g = e.phys[0], mass = e.phys[1], L = e.phys[2], Ixx = e.phys[3], Iyy = e.phys[4],
+                 Izz = e.phys[5], kM = e.phys[6];
+    X ph = x[3], th = x[4], ps = x[5], p = x[9], q = x[10], r = x[11];
+    X sph = sin(ph), cph = cos(ph), sth = sin(th), cth = cos(th), sps = sin(ps), cps = cos(ps);
+    X F = u[0] + u[1] + u[2] + u[3];
+    X tx = L * (u[1] - u[3]), ty = L * (u[2] - u[0]), tz = kM * (u[0] - u[1] + u[2] - u[3]);
+    X tth = sth / cth;
+    dx[0] = x[6]; dx[1] = x[7]; dx[2] = x[8];
+    dx[3] = p + sph * tth * q + cph * tth * r;
+    dx[4] = cph * q - sph * r;
+    dx[5] = (sph * q + cph * r) / cth;
+    dx[6] = (cph * sth * cps + sph * sps) * F / mass;
+    dx[7] = (cph * sth * sps - sph * cps) * F / mass;
+    dx[8] = cph * cth * F / mass - g;
+    dx[9] = (tx - (Izz - Iyy) * q * r) / Ixx;
+    dx[10] = (ty - (Ixx - Izz) * p * r) / Iyy;
+    dx[11] = (tz - (Iyy - Ixx) * p * q) / Izz;
+}
+
+template <class X> void vector_field(const trajopt_env_t& e, const X* x, const X* u, X* dx) {
+    switch (e.model) {
+        case TRAJOPT_ENV_PENDULUM: f_pendulum(e, x, u, dx); break;
+        case TRAJOPT_ENV_CARTPOLE: f_cartpole(e, x, u, dx); break;
+        case TRAJOPT_ENV_DOUBLE_CARTPOLE: f_double_cartpole(e, x, u, dx); break;
+        case TRAJOPT_ENV_QUADROTOR: f_quadrotor(e, x, u, dx); break;
+        default: break;
+    }
+}
+
+// env.dynamics(x, u): clip(u) -> RK4 -> clip(xn)   (cartpole.py:62-97); LQR: A x + B clip(u) + c, no
+// state clip (lqr_v0.py:50-66).
+template <class X> void dynamics(const trajopt_env_t& e, const X* x, const X* u, X* xn) {
+    const int n = e.dm_state, m = e.dm_act;
+    X uc[TRAJOPT_ENV_MAX_ACT];
+    for (int j = 0; j < m; ++j) uc[j] = clip(u[j], e.umax[j]);
+    if (e.model == TRAJOPT_ENV_LQR) {
+        for (int i = 0; i < n; ++i) {
+            X s(0.);
+            for (int j = 0; j < n; ++j) s = s + e.lin_A[i + n * j] * x[j];
+            X s2(0.);
+            for (int j = 0; j < m; ++j) s2 = s2 + e.lin_B[i + n * j] * uc[j];
+            xn[i] = s + s2 + e.lin_c[i];
+        }
+        return;
+    }
+    const double dt = e.dt;
+    X k1[TRAJOPT_ENV_MAX_STATE], k2[TRAJOPT_ENV_MAX_STATE], k3[TRAJOPT_ENV_MAX_STATE], k4[TRAJOPT_ENV_MAX_STATE],
+        y[TRAJOPT_ENV_MAX_STATE];
+    vector_field(e, x, uc, k1);
+    for (int i = 0; i < n; ++i) y[i] = x[i] + 0.5 * dt * k1[i];
+    vector_field(e, y, uc, k2);
+    for (int i = 0; i < n; ++i) y[i] = x[i] + 0.5 * dt * k2[i];
+    vector_field(e, y, uc, k3);
+    for (int i = 0; i < n; ++i) y[i] = x[i] + dt * k3[i];
+    vector_field(e, y, uc, k4);
+    for (int i = 0; i < n; ++i) {
+        X s = x[i] + dt / 6. * (k1[i] + 2. * k2[i] + 2. * k3[i] + k4[i]);
+        xn[i] = clip(s, e.xmax[i]);
+    }
+}
+
+inline double wrap_angle(double x) {  // cartpole.py:10-12, Python's % (sign of the divisor)
+    double r = std::fmod(x + M_PI, 2. * M_PI);
+    if (r < 0) r += 2. * M_PI;
+    return r - M_PI;
+}
+
+// env.cost(x, u, u_last, a) with identity features (cartpole.py:99-105,112-127): J = I, j = 0.
+inline double cost(const trajopt_env_t& e, const double* x, const double* u, const double* u_last, double a) {
+    const int n = e.dm_state, m = e.dm_act;
+    double c = 0.;
+    for (int j = 0; j < m; ++j) {
+        const double d = e.slew_rate ? (u[j] - u_last[j]) : u[j];
+        c += d * e.uw[j] * d;
+    }
+    if (a != 0.) {  // Python `if a:` (cartpole.py:120): an exactly-zero weight drops the state cost
+        double s = 0.;
+        for (int i = 0; i < n; ++i) {
+            const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
+            s += (y - e.goal[i]) * e.gw[i] * (y - e.goal[i]);
+        }
+        c += a * s;
+    }
+    return e.cost_times_dt ? e.dt * c : c;
+}
+
+// autograd derivatives of cost() in the iLQR convention (ilqr/objects.py:72-78): no 1/2, no de-centring.
+inline void cost_derivatives(const trajopt_env_t& e, const double* x, const double* u, const double* u_last,
+                             double a, double* Cxx, double* cx, double* Cuu, double* cu, double* Cxu) {
+    const int n = e.dm_state, m = e.dm_act;
+    const double sc = e.cost_times_dt ? e.dt : 1.0;
+    for (int k = 0; k < n * n; ++k) Cxx[k] = 0.;
+    for (int k = 0; k < m * m; ++k) Cuu[k] = 0.;
+    for (int k = 0; k < n * m; ++k) Cxu[k] = 0.;
+    for (int j = 0; j < m; ++j) {
+        const double d = e.slew_rate ? (u[j] - u_last[j]) : u[j];
+        Cuu[j + m * j] = sc * 2. * e.uw[j];
+        cu[j] = sc * 2. * e.uw[j] * d;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (a != 0.) {
+            const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
+            Cxx[i + n * i] = sc * 2. * a * e.gw[i];
+            cx[i] = sc * 2. * a * e.gw[i] * (y - e.goal[i]);
+        } else {
+            cx[i] = 0.;
+        }
+    }
+}
+
+// A4: A = d dynamics / dx, B = d dynamics / du at (x, u)  (ilqr/objects.py:114-117), column-major.
+template <int N, int Mm>
+void dynamics_jacobians_T(const trajopt_env_t& e, const double* x, const double* u, double* A, double* B,
+                          double* xn_out) {
+    using D = Dual<N + Mm>;
+    D xd[TRAJOPT_ENV_MAX_STATE], ud[TRAJOPT_ENV_MAX_ACT], xn[TRAJOPT_ENV_MAX_STATE];
+    for (int i = 0; i < N; ++i) { xd[i] = D(x[i]); xd[i].d[i] = 1.0; }
+    for (int j = 0; j < Mm; ++j) { ud[j] = D(u[j]); ud[j].d[N + j] = 1.0; }
+    dynamics(e, xd, ud, xn);
+    for (int i = 0; i < N; ++i) {
+        for (int j = 0; j < N; ++j) A[i + N * j] = xn[i].d[j];
+        for (int j = 0; j < Mm; ++j) B[i + N * j] = xn[i].d[N + j];
+        if (xn_out) xn_out[i] = xn[i].v;
+    }
+}
+inline int dynamics_jacobians(const trajopt_env_t& e, const double* x, const double* u, double* A, double* B,
+                              double* xn_out) {
+    const int n = e.dm_state, m = e.dm_act;
+    if (n == 2 && m == 1) dynamics_jacobians_T<2, 1>(e, x, u, A, B, xn_out);
+    else if (n == 4 && m == 1) dynamics_jacobians_T<4, 1>(e, x, u, A, B, xn_out);
+    else if (n == 6 && m == 1) dynamics_jacobians_T<6, 1>(e, x, u, A, B, xn_out);
+    else if (n == 12 && m == 4) dynamics_jacobians_T<12, 4>(e, x, u, A, B, xn_out);
+    else if (n == 2 && m == 2) dynamics_jacobians_T<2, 2>(e, x, u, A, B, xn_out);
+    else if (n == 4 && m == 2) dynamics_jacobians_T<4, 2>(e, x, u, A, B, xn_out);
+    else if (n == 3 && m == 1) dynamics_jacobians_T<3, 1>(e, x, u, A, B, xn_out);
+    else return -1;
+    return 0;
+}
+
+}  // namespace oracle

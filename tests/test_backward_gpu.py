@@ -1,0 +1,184 @@
+"""GPU parity of the HIP backward passes (rows A1, A9) against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from tests.util import TOL, assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+OUT = ("Qxx", "Qux", "Quu", "qx", "qu", "V", "v", "dV", "K", "kff")
+
+
+def _run_gpu(stack, lmbda, reg, n, m, T, N, layout, full=True, retry=False, sched=None, uref=None):
+    import torch
+    from trajopt_amd import backward, layout as L
+    d = {k: L.to_device(v, layout) for k, v in stack.items()}
+    lam = torch.full((N,), float(lmbda), dtype=torch.float64, device="cuda") if np.isscalar(lmbda) else \
+        torch.tensor(lmbda, dtype=torch.float64, device="cuda")
+    dl = torch.ones(N, dtype=torch.float64, device="cuda") if retry else None
+    u = L.to_device(uref, layout) if uref is not None else None
+    o = backward.ilqr_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"], lam, reg, n, m, T,
+                                    N, layout, full=full, retry=retry, sched=sched, dlmbda=dl, uref=u)
+    torch.cuda.synchronize()
+    res = {k: L.from_device(o[k], layout) for k in o if k not in ("diverge", "g_norm")}
+    res["diverge"] = o["diverge"].cpu().numpy()
+    if "g_norm" in o:
+        res["g_norm"] = o["g_norm"].cpu().numpy()
+    res["lmbda"] = lam.cpu().numpy()
+    if dl is not None:
+        res["dlmbda"] = dl.cpu().numpy()
+    return res
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("n,m,T,N", [(2, 1, 100, 3), (3, 1, 33, 65), (4, 1, 64, 130), (4, 2, 40, 67), (6, 1, 48, 70),
+                                      (12, 4, 32, 5), (5, 3, 20, 4), (64, 16, 6, 2)])
+@pytest.mark.parametrize("reg", [1, 2])
+def test_ilqr_backward_matches_oracle(oracle, n, m, T, N, layout, reg):
+    from trajopt_amd import synthetic as S
+    stack = S.backward_inputs(n, m, T, N, seed=1337 + n)
+    res = _run_gpu(stack, 1.0, reg, n, m, T, N, layout)
+    for p in range(N):
+        q = S.problem(stack, p)
+        ref, failed = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], 1.0, reg, n,
+                                           m, T)
+        assert not failed and res["diverge"][p] == -1
+        for k, r in zip(OUT, ref[:10]):
+            assert_close(res[k][p], r, "%s[p=%d]" % (k, p))
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("n,m,T,N", [(4, 1, 500, 64), (6, 1, 500, 64)])
+def test_gains_only_long_horizon(oracle, n, m, T, N, layout):
+    """BASELINE shapes C2/C3 at full T; gains-only outputs (what the fused iteration uses)."""
+    from trajopt_amd import synthetic as S
+    stack = S.backward_inputs(n, m, T, N)
+    res = _run_gpu(stack, 1.0, 1, n, m, T, N, layout, full=False)
+    assert "V" not in res
+    for p in range(0, N, 7):
+        q = S.problem(stack, p)
+        ref, _ = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], 1.0, 1, n, m, T)
+        assert_close(res["K"][p], ref[8], "K")
+        assert_close(res["kff"][p], ref[9], "kff")
+        assert_close(res["dV"][p], ref[7], "dV")
+
+
+def _indefinite(stack, at, N):
+    """Make Cuu strongly negative at time index `at` for odd problems."""
+    Cuu = np.array(stack["Cuu"])
+    m = Cuu.shape[1]
+    for p in range(1, N, 2):
+        Cuu[p, :, :, at] = -50.0 * np.eye(m)
+    out = dict(stack)
+    out["Cuu"] = Cuu
+    return out
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("n,m", [(2, 1), (4, 1), (4, 2), (12, 4)])
+def test_divergence_index_and_partial_outputs(oracle, n, m, layout):
+    from trajopt_amd import synthetic as S
+    T, N, at = 24, 6, 9
+    stack = _indefinite(S.backward_inputs(n, m, T, N, seed=5), at, N)
+    res = _run_gpu(stack, 1e-3, 1, n, m, T, N, layout)
+    for p in range(N):
+        q = S.problem(stack, p)
+        ref, failed = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], 1e-3, 1, n,
+                                           m, T)
+        if p % 2 == 1:
+            assert failed and ref[10] == at and res["diverge"][p] == at
+            # slices above the failing step are valid; the Q blocks OF the failing step are written too
+            assert_close(res["V"][p][..., at + 1:], ref[5][..., at + 1:], "V")
+            assert_close(res["K"][p][..., at + 1:], ref[8][..., at + 1:], "K")
+            assert_close(res["Qxx"][p][..., at:], ref[0][..., at:], "Qxx")
+            assert_close(res["Quu"][p][..., at:], ref[2][..., at:], "Quu")
+            # nothing below the failing step is touched (the wrapper zero-fills like the oracle)
+            assert not np.any(res["K"][p][..., :at + 1]) and not np.any(res["V"][p][..., :at + 1])
+        else:
+            assert not failed and res["diverge"][p] == -1
+            assert_close(res["K"][p], ref[8], "K")
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("n,m", [(4, 1), (12, 4)])
+def test_in_kernel_lambda_retry_matches_driver_loop(oracle, n, m, layout):
+    """ilqr.py:162-173 folded into the kernel: same final lmbda/dlmbda and gains as looping the oracle."""
+    from trajopt_amd import synthetic as S
+    from trajopt_amd._lib import LambdaSchedule
+    T, N, at = 16, 5, 4
+    stack = _indefinite(S.backward_inputs(n, m, T, N, seed=11), at, N)
+    sched = LambdaSchedule(1e-6, 1e6, 1.6)
+    res = _run_gpu(stack, 1.0, 1, n, m, T, N, layout, retry=True, sched=sched)
+    for p in range(N):
+        q = S.problem(stack, p)
+        lam, dlam = 1.0, 1.0
+        while True:
+            ref, failed = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], lam, 1,
+                                               n, m, T)
+            if not failed:
+                break
+            dlam = max(dlam * 1.6, 1.6)
+            lam = max(lam * dlam, 1e-6)
+            if lam > 1e6:
+                break
+        assert res["lmbda"][p] == pytest.approx(lam, rel=1e-15)
+        assert res["dlmbda"][p] == pytest.approx(dlam, rel=1e-15)
+        assert (res["diverge"][p] >= 0) == failed
+        if not failed:
+            assert_close(res["K"][p], ref[8], "K")
+            assert_close(res["kff"][p], ref[9], "kff")
+            assert_close(res["dV"][p], ref[7], "dV")
+    # lambda above max: gives up with the flag set (ilqr.py:168)
+    sched2 = LambdaSchedule(1e-6, 10.0, 1.6)
+    res2 = _run_gpu(stack, 1.0, 1, n, m, T, N, layout, retry=True, sched=sched2)
+    assert all(res2["diverge"][p] == at for p in range(1, N, 2))
+    assert all(res2["lmbda"][p] > 10.0 for p in range(1, N, 2))
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_gradient_norm_output(oracle, layout):
+    from trajopt_amd import synthetic as S
+    n, m, T, N = 4, 2, 20, 9
+    stack = S.backward_inputs(n, m, T, N, seed=3)
+    uref = np.random.default_rng(0).standard_normal((N, m, T))
+    res = _run_gpu(stack, 1.0, 1, n, m, T, N, layout, full=False, uref=uref)
+    for p in range(N):
+        g = np.mean(np.max(np.abs(res["kff"][p]) / (np.abs(uref[p]) + 1.0), axis=1))  # ilqr.py:176
+        assert res["g_norm"][p] == pytest.approx(g, rel=1e-14)
+
+
+def test_host_entry_point_is_the_reference_signature(oracle):
+    """trajopt.ilqr.core.backward_pass drop-in: host arrays in, 11-tuple of F-ordered arrays out."""
+    from trajopt_amd import synthetic as S
+    from trajopt_amd.ilqr.core import backward_pass
+    for (n, m, T) in [(2, 1, 100), (4, 1, 50), (12, 4, 20)]:
+        q = S.problem(S.backward_inputs(n, m, T, 1), 0)
+        # C-ordered inputs, as the reference's Python side allocates them (np.zeros((n, n, T)))
+        args = [np.ascontiguousarray(q[k]) for k in ("Cxx", "cx", "Cuu", "cu", "Cxu", "A", "B")]
+        out = backward_pass(*args, 1.0, 1, n, m, T)
+        ref, _ = oracle.backward_pass(*args, 1.0, 1, n, m, T)
+        assert len(out) == 11 and out[10] == 0
+        for k, a, r in zip(OUT, out[:10], ref[:10]):
+            assert a.flags.f_contiguous and a.dtype == np.float64
+            assert_close(a, r, k)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("n,m,T,N", [(2, 1, 60, 3), (4, 1, 40, 5), (6, 2, 30, 4), (12, 4, 24, 3), (64, 16, 5, 2)])
+def test_riccati_backward_matches_oracle(oracle, n, m, T, N, layout):
+    import torch
+    from trajopt_amd import backward, layout as L, synthetic as S
+    stack = S.backward_inputs(n, m, T, N, seed=77, affine=True)
+    d = {k: L.to_device(v, layout) for k, v in stack.items()}
+    o = backward.riccati_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"], d["c"], n, m, T,
+                                       N, layout)
+    torch.cuda.synchronize()
+    assert not o["status"].cpu().numpy().any()
+    for p in range(N):
+        q = S.problem(stack, p)
+        K, kff, V, v = oracle.riccati_backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"],
+                                                    q["c"], n, m, T)
+        assert_close(L.from_device(o["K"], layout)[p], K, "K")
+        assert_close(L.from_device(o["kff"], layout)[p], kff, "kff")
+        assert_close(L.from_device(o["V"], layout)[p], V, "V")
+        assert_close(L.from_device(o["v"], layout)[p], v, "v")

@@ -1,0 +1,123 @@
+"""ctypes binding of libtrajopt_amd.so - the C ABI declared in include/trajopt_amd.h.
+
+The library is built in-tree by `make -C trajopt_amd/csrc` (or __graft_entry__.build()).  There is no
+CPU fallback: if the shared object is missing, or no HIP device is present when a compute entry
+point is called, a TrajoptError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libtrajopt_amd.so")
+
+LAYOUT_PROBLEM_MAJOR = 0
+LAYOUT_PROBLEM_MINOR = 1
+MAX_ALPHAS = 16
+MAX_STATE, MAX_ACT = 12, 4
+
+ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR = 1, 2, 3, 4, 5
+
+
+class TrajoptError(RuntimeError):
+    pass
+
+
+class EnvStruct(C.Structure):
+    """include/trajopt_env.h::trajopt_env_t"""
+    _fields_ = [("model", C.c_int32), ("dm_state", C.c_int32), ("dm_act", C.c_int32),
+                ("slew_rate", C.c_int32), ("periodic", C.c_int32), ("cost_times_dt", C.c_int32),
+                ("dt", C.c_double),
+                ("umax", C.c_double * MAX_ACT), ("xmax", C.c_double * MAX_STATE),
+                ("goal", C.c_double * MAX_STATE), ("gw", C.c_double * MAX_STATE),
+                ("uw", C.c_double * MAX_ACT),
+                ("lin_A", C.c_double * (MAX_STATE * MAX_STATE)),
+                ("lin_B", C.c_double * (MAX_STATE * MAX_ACT)),
+                ("lin_c", C.c_double * MAX_STATE),
+                ("phys", C.c_double * 16)]
+
+
+class LambdaSchedule(C.Structure):
+    _fields_ = [("min_lmbda", C.c_double), ("max_lmbda", C.c_double), ("mult_lmbda", C.c_double)]
+
+
+_dp = C.c_void_p  # device pointers travel as integers
+
+
+class BackwardIO(C.Structure):
+    """include/trajopt_amd.h::trajopt_backward_io_t"""
+    _fields_ = [(k, _dp) for k in
+                ("Cxx", "cx", "Cuu", "cu", "Cxu", "A", "B", "lmbda", "dlmbda",
+                 "Qxx", "Qux", "Quu", "qx", "qu", "V", "v", "dV", "K", "kff", "diverge",
+                 "uref", "g_norm", "active")]
+
+
+class ILQROptions(C.Structure):
+    _fields_ = [("sched", LambdaSchedule), ("tolfun", C.c_double), ("tolgrad", C.c_double),
+                ("min_imp", C.c_double), ("reg", C.c_int32), ("nb_alphas", C.c_int32),
+                ("alphas", C.c_double * MAX_ALPHAS), ("argmin_alpha", C.c_int32), ("keep_value", C.c_int32)]
+
+
+class ILQRWorkspace(C.Structure):
+    _fields_ = ([("nb_steps", C.c_int32), ("pad_", C.c_int32), ("nb_problems", C.c_int64)] +
+                [(k, _dp) for k in
+                 ("x0", "weighting", "xref", "uref", "K", "kff", "V", "v", "Qxx", "Qux", "Quu", "qx", "qu",
+                  "last_return", "lmbda", "dlmbda", "alpha", "status", "iters", "trace_len", "trace")] +
+                [("trace_cap", C.c_int32), ("pad2_", C.c_int32)] +
+                [(k, _dp) for k in
+                 ("A", "B", "Cxx", "cx", "Cuu", "cu", "Cxu", "cand_K", "cand_kff", "cand_V", "cand_v", "cand_Qxx",
+                  "cand_Qux", "cand_Quu", "cand_qx", "cand_qu", "dV", "g_norm", "diverge", "active", "sel",
+                  "cand_state", "cand_action", "cand_ret", "cand_finite")])
+
+
+# every symbol include/trajopt_amd.h declares
+EXPORTS = (
+    "trajopt_abi_version", "trajopt_error_string", "trajopt_last_hip_error", "trajopt_device_count",
+    "trajopt_ilqr_backward_pass_host", "trajopt_ilqr_backward_pass_batched",
+    "trajopt_riccati_backward_pass_host", "trajopt_riccati_backward_pass_batched",
+    "trajopt_env_step_batched", "trajopt_ilqr_forward_pass_batched", "trajopt_quadratize_batched",
+    "trajopt_ilqr_init_rollout", "trajopt_ilqr_iterate", "trajopt_convert_layout",
+)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise TrajoptError(
+                "%s is missing: build it with `make -C trajopt_amd/csrc` (there is no CPU fallback)" % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        L.trajopt_error_string.restype = C.c_char_p
+        L.trajopt_last_hip_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        L = lib()
+        msg = L.trajopt_error_string(rc).decode()
+        hip = L.trajopt_last_hip_error().decode()
+        raise TrajoptError("trajopt_amd: %s (%d)%s" % (msg, rc, (" - " + hip) if hip and rc == -3 else ""))
+
+
+def device_count():
+    return lib().trajopt_device_count()
+
+
+def require_gpu():
+    n = device_count()
+    if n <= 0:
+        raise TrajoptError("trajopt_amd needs a HIP device; none is visible (there is no CPU fallback)")
+    return n
+
+
+def dptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

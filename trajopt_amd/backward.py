@@ -1,0 +1,80 @@
+"""Batched backward passes on device tensors (rows A1 and A9 of the hot path).
+
+Thin plumbing over the C ABI: torch only provides device memory and the current stream.
+"""
+import ctypes as C
+
+from . import _lib
+from ._lib import BackwardIO, LambdaSchedule, LAYOUT_PROBLEM_MAJOR, LAYOUT_PROBLEM_MINOR, check, dptr, lib, stream_ptr
+from .layout import empty
+
+
+def _chk(t, numel, name):
+    import torch
+    if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or t.numel() != numel:
+        raise ValueError("%s must be a contiguous CUDA float64 tensor with %d elements" % (name, numel))
+
+
+def ilqr_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, dm_state, dm_act, nb_steps, nb_problems, layout,
+                       full=True, retry=False, sched=None, dlmbda=None, uref=None, active=None, out=None):
+    """Regularised Riccati recursion of /root/reference/trajopt/ilqr/src/util.cpp:83-182 for a batch.
+
+    Inputs are device tensors in `layout` (see layout.py); `lmbda` is a [N] tensor (updated in place when
+    retry=True).  Returns a dict with K, kff, dV, diverge (and Qxx, Qux, Quu, qx, qu, V, v when full=True,
+    g_norm when uref is given).  diverge[p] = -1 when every step passed the PD test.
+    """
+    import torch
+    _lib.require_gpu()
+    n, m, T, N = dm_state, dm_act, nb_steps, nb_problems
+    for t, cnt, nm in ((Cxx, n * n * (T + 1), "Cxx"), (cx, n * (T + 1), "cx"), (Cuu, m * m * (T + 1), "Cuu"),
+                       (cu, m * (T + 1), "cu"), (Cxu, n * m * (T + 1), "Cxu"), (A, n * n * T, "A"),
+                       (B, n * m * T, "B")):
+        _chk(t, cnt * N, nm)
+    _chk(lmbda, N, "lmbda")
+    dev = Cxx.device
+    o = {} if out is None else out
+    o.setdefault("K", empty((N, m, n, T), layout, dev, zero=True))
+    o.setdefault("kff", empty((N, m, T), layout, dev, zero=True))
+    o.setdefault("dV", empty((N, 2), layout, dev, zero=True))
+    if "diverge" not in o:
+        o["diverge"] = torch.empty(N, dtype=torch.int32, device=dev)
+    if full:
+        o.setdefault("Qxx", empty((N, n, n, T), layout, dev, zero=True))
+        o.setdefault("Qux", empty((N, m, n, T), layout, dev, zero=True))
+        o.setdefault("Quu", empty((N, m, m, T), layout, dev, zero=True))
+        o.setdefault("qx", empty((N, n, T), layout, dev, zero=True))
+        o.setdefault("qu", empty((N, m, T), layout, dev, zero=True))
+        o.setdefault("V", empty((N, n, n, T + 1), layout, dev, zero=True))
+        o.setdefault("v", empty((N, n, T + 1), layout, dev, zero=True))
+    if uref is not None and "g_norm" not in o:
+        o["g_norm"] = torch.empty(N, dtype=torch.float64, device=dev)
+    io = BackwardIO()
+    io.Cxx, io.cx, io.Cuu, io.cu, io.Cxu, io.A, io.B = map(dptr, (Cxx, cx, Cuu, cu, Cxu, A, B))
+    io.lmbda, io.dlmbda = dptr(lmbda), dptr(dlmbda)
+    for k in ("Qxx", "Qux", "Quu", "qx", "qu", "V", "v"):
+        setattr(io, k, dptr(o.get(k)) if full else None)
+    io.dV, io.K, io.kff, io.diverge = dptr(o["dV"]), dptr(o["K"]), dptr(o["kff"]), dptr(o["diverge"])
+    io.uref, io.g_norm, io.active = dptr(uref), dptr(o.get("g_norm")), dptr(active)
+    s = sched if sched is not None else LambdaSchedule(1e-6, 1e6, 1.6)
+    check(lib().trajopt_ilqr_backward_pass_batched(C.byref(io), int(reg), n, m, T, C.c_int64(N), int(layout),
+                                                   int(bool(retry)), C.byref(s), stream_ptr()))
+    return o
+
+
+def riccati_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, c, dm_state, dm_act, nb_steps, nb_problems, layout):
+    """TV-LQR sweep of /root/reference/trajopt/riccati/riccati.py:100-126 for a batch -> K, kff, V, v, status."""
+    import torch
+    _lib.require_gpu()
+    n, m, T, N = dm_state, dm_act, nb_steps, nb_problems
+    for t, cnt, nm in ((Cxx, n * n * (T + 1), "Cxx"), (cx, n * (T + 1), "cx"), (Cuu, m * m * (T + 1), "Cuu"),
+                       (cu, m * (T + 1), "cu"), (Cxu, n * m * (T + 1), "Cxu"), (A, n * n * T, "A"),
+                       (B, n * m * T, "B"), (c, n * T, "c")):
+        _chk(t, cnt * N, nm)
+    dev = Cxx.device
+    o = dict(K=empty((N, m, n, T), layout, dev, zero=True), kff=empty((N, m, T), layout, dev, zero=True),
+             V=empty((N, n, n, T + 1), layout, dev, zero=True), v=empty((N, n, T + 1), layout, dev, zero=True),
+             status=torch.zeros(N, dtype=torch.int32, device=dev))
+    check(lib().trajopt_riccati_backward_pass_batched(
+        dptr(Cxx), dptr(cx), dptr(Cuu), dptr(cu), dptr(Cxu), dptr(A), dptr(B), dptr(c), n, m, T, C.c_int64(N),
+        int(layout), dptr(o["V"]), dptr(o["v"]), dptr(o["K"]), dptr(o["kff"]), dptr(o["status"]), stream_ptr()))
+    return o

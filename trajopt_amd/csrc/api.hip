@@ -1,0 +1,236 @@
+// extern "C" entry points of libtrajopt_amd.so (declared in include/trajopt_amd.h) for the backward
+// passes, plus the small utilities.  No CPU fallback exists anywhere: without a HIP device every
+// compute entry point returns TRAJOPT_ERR_NO_DEVICE / TRAJOPT_ERR_HIP.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "common.h"
+
+namespace trajopt {
+
+static thread_local char g_hip_err[512] = "";
+void set_hip_error(hipError_t e, const char* where) {
+    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
+}
+
+extern int g_tpp_dbg_same_step;
+static int g_force_kernel = 0;  // 0 auto, 1 always the workgroup-per-problem kernel (tests)
+
+template <bool TO_MINOR>
+__global__ void convert_layout_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t E, size_t NP) {
+    // grid-stride over all E*NP elements; index by destination so stores are coalesced
+    const size_t total = E * NP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        if (TO_MINOR) {  // dst[e*NP + p] = src[p*E + e]
+            const size_t e = i / NP, p = i % NP;
+            dst[i] = src[p * E + e];
+        } else {         // dst[p*E + e] = src[e*NP + p]
+            const size_t p = i / E, e = i % E;
+            dst[i] = src[e * NP + p];
+        }
+    }
+}
+
+// RAII device buffer for the *_host convenience wrappers only (the batched API never allocates).
+struct DevBuf {
+    double* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { n = count; return hipMalloc(&p, (count ? count : 1) * sizeof(double)); }
+};
+
+static bool tpp_offsets_fit(int n, int64_t NP) { return (double)n * n * (double)NP * 8.0 + 512.0 < 4294967296.0; }
+
+}  // namespace trajopt
+
+using namespace trajopt;
+
+extern "C" {
+
+int trajopt_abi_version(void) { return TRAJOPT_ABI_VERSION; }
+
+const char* trajopt_error_string(int code) {
+    switch (code) {
+        case TRAJOPT_OK: return "ok";
+        case TRAJOPT_ERR_BAD_ARG: return "bad argument";
+        case TRAJOPT_ERR_UNSUPPORTED: return "unsupported shape";
+        case TRAJOPT_ERR_HIP: return "HIP runtime error";
+        case TRAJOPT_ERR_NO_DEVICE: return "no HIP device (there is no CPU fallback)";
+        default: return "unknown error";
+    }
+}
+
+const char* trajopt_last_hip_error(void) { return g_hip_err; }
+
+int trajopt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return TRAJOPT_ERR_NO_DEVICE;
+    return n;
+}
+
+int trajopt_debug_force_kernel(int which) {
+    g_force_kernel = which;
+    return TRAJOPT_OK;
+}
+
+int trajopt_debug_tpp_same_step(int on) {
+    g_tpp_dbg_same_step = on;
+    return TRAJOPT_OK;
+}
+
+int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg, int n, int m, int T, int64_t NP,
+                                       int layout, int retry, const trajopt_lambda_schedule_t* sched,
+                                       void* stream) {
+    if (!io || n <= 0 || m <= 0 || T <= 0 || NP <= 0) return TRAJOPT_ERR_BAD_ARG;
+    if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
+    if (!io->Cxx || !io->cx || !io->Cuu || !io->cu || !io->Cxu || !io->A || !io->B || !io->lmbda || !io->dV ||
+        !io->K || !io->kff || !io->diverge)
+        return TRAJOPT_ERR_BAD_ARG;
+    if (retry && !sched) return TRAJOPT_ERR_BAD_ARG;
+    trajopt_lambda_schedule_t s = sched ? *sched : trajopt_lambda_schedule_t{1e-6, 1e6, 1.6};
+    hipStream_t st = as_stream(stream);
+    // NP == 1: the two layouts are the same memory
+    if ((layout == TRAJOPT_LAYOUT_PROBLEM_MINOR || NP == 1) && g_force_kernel == 0 && tpp_offsets_fit(n, NP)) {
+        bool handled = false;
+        const int rc = launch_backward_tpp(*io, reg, n, m, T, NP, retry, s, st, &handled);
+        if (rc != TRAJOPT_OK || handled) return rc;
+    }
+    return launch_backward_wg(*io, reg, n, m, T, NP, layout, retry, s, st);
+}
+
+int trajopt_riccati_backward_pass_batched(const double* Cxx, const double* cx, const double* Cuu, const double* cu,
+                                          const double* Cxu, const double* A, const double* B, const double* c,
+                                          int n, int m, int T, int64_t NP, int layout, double* V, double* v,
+                                          double* K, double* kff, int32_t* status, void* stream) {
+    if (!Cxx || !cx || !Cuu || !cu || !Cxu || !A || !B || !c || !V || !v || !K || !kff) return TRAJOPT_ERR_BAD_ARG;
+    if (n <= 0 || m <= 0 || T <= 0 || NP <= 0) return TRAJOPT_ERR_BAD_ARG;
+    if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
+    return launch_riccati_wg(Cxx, cx, Cuu, cu, Cxu, A, B, c, n, m, T, NP, layout, V, v, K, kff, status,
+                             as_stream(stream));
+}
+
+int trajopt_convert_layout(const double* src, double* dst, int64_t E, int64_t NP, int src_layout, int dst_layout,
+                           void* stream) {
+    if (!src || !dst || E <= 0 || NP <= 0) return TRAJOPT_ERR_BAD_ARG;
+    hipStream_t st = as_stream(stream);
+    if (src_layout == dst_layout || NP == 1 || E == 1) {
+        TRAJOPT_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)E * NP * sizeof(double), hipMemcpyDeviceToDevice, st));
+        return TRAJOPT_OK;
+    }
+    const size_t total = (size_t)E * NP;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dst_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR)
+        hipLaunchKernelGGL(convert_layout_kernel<true>, dim3(grid), dim3(256), 0, st, src, dst, (size_t)E, (size_t)NP);
+    else
+        hipLaunchKernelGGL(convert_layout_kernel<false>, dim3(grid), dim3(256), 0, st, src, dst, (size_t)E, (size_t)NP);
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+// ---- host-pointer wrappers: the exact shape of the reference's pybind11 entry ------------------------
+int trajopt_ilqr_backward_pass_host(const double* Cxx, const double* cx, const double* Cuu, const double* cu,
+                                    const double* Cxu, const double* A, const double* B, double lmbda, int reg,
+                                    int n, int m, int T, double* Qxx, double* Qux, double* Quu, double* qx,
+                                    double* qu, double* V, double* v, double* dV, double* K, double* kff,
+                                    int* diverge, int* failed) {
+    if (!Cxx || !cx || !Cuu || !cu || !Cxu || !A || !B || !Qxx || !Qux || !Quu || !qx || !qu || !V || !v || !dV ||
+        !K || !kff || !diverge)
+        return TRAJOPT_ERR_BAD_ARG;
+    if (n <= 0 || m <= 0 || T <= 0) return TRAJOPT_ERR_BAD_ARG;
+    if (trajopt_device_count() < 0) return TRAJOPT_ERR_NO_DEVICE;
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
+    // one allocation: inputs | outputs | scalars
+    const size_t in_counts[7] = {nn * (T + 1), (size_t)n * (T + 1), mm * (T + 1), (size_t)m * (T + 1), nm * (T + 1),
+                                 nn * T, nm * T};
+    const double* in_host[7] = {Cxx, cx, Cuu, cu, Cxu, A, B};
+    const size_t out_counts[10] = {nn * T, nm * T, mm * T, (size_t)n * T, (size_t)m * T, nn * (T + 1),
+                                   (size_t)n * (T + 1), 2, nm * T, (size_t)m * T};
+    double* out_host[10] = {Qxx, Qux, Quu, qx, qu, V, v, dV, K, kff};
+    size_t total = 0;
+    for (size_t c : in_counts) total += c;
+    size_t in_total = total;
+    for (size_t c : out_counts) total += c;
+    total += 2;  // lmbda, (int) diverge
+    DevBuf buf;
+    TRAJOPT_HIP_CHECK(buf.alloc(total));
+    hipStream_t st = nullptr;
+    double* d = buf.p;
+    const double* din[7];
+    for (int i = 0; i < 7; ++i) {
+        TRAJOPT_HIP_CHECK(hipMemcpyAsync(d, in_host[i], in_counts[i] * sizeof(double), hipMemcpyHostToDevice, st));
+        din[i] = d;
+        d += in_counts[i];
+    }
+    TRAJOPT_HIP_CHECK(hipMemsetAsync(buf.p + in_total, 0, (total - in_total) * sizeof(double), st));
+    double* dout[10];
+    for (int i = 0; i < 10; ++i) {
+        dout[i] = d;
+        d += out_counts[i];
+    }
+    double* d_lmbda = d;
+    int32_t* d_div = reinterpret_cast<int32_t*>(d + 1);
+    TRAJOPT_HIP_CHECK(hipMemcpyAsync(d_lmbda, &lmbda, sizeof(double), hipMemcpyHostToDevice, st));
+    trajopt_backward_io_t io{};
+    io.Cxx = din[0]; io.cx = din[1]; io.Cuu = din[2]; io.cu = din[3]; io.Cxu = din[4]; io.A = din[5]; io.B = din[6];
+    io.lmbda = d_lmbda;
+    io.Qxx = dout[0]; io.Qux = dout[1]; io.Quu = dout[2]; io.qx = dout[3]; io.qu = dout[4]; io.V = dout[5];
+    io.v = dout[6]; io.dV = dout[7]; io.K = dout[8]; io.kff = dout[9];
+    io.diverge = d_div;
+    const int rc = trajopt_ilqr_backward_pass_batched(&io, reg, n, m, T, 1, TRAJOPT_LAYOUT_PROBLEM_MAJOR, 0, nullptr, st);
+    if (rc != TRAJOPT_OK) return rc;
+    for (int i = 0; i < 10; ++i)
+        TRAJOPT_HIP_CHECK(hipMemcpyAsync(out_host[i], dout[i], out_counts[i] * sizeof(double), hipMemcpyDeviceToHost, st));
+    int32_t div = -1;
+    TRAJOPT_HIP_CHECK(hipMemcpyAsync(&div, d_div, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TRAJOPT_HIP_CHECK(hipStreamSynchronize(st));
+    *diverge = div < 0 ? 0 : div;  // util.cpp:120,146
+    if (failed) *failed = div >= 0 ? 1 : 0;
+    return TRAJOPT_OK;
+}
+
+int trajopt_riccati_backward_pass_host(const double* Cxx, const double* cx, const double* Cuu, const double* cu,
+                                       const double* Cxu, const double* A, const double* B, const double* c, int n,
+                                       int m, int T, double* V, double* v, double* K, double* kff, int* status) {
+    if (!Cxx || !cx || !Cuu || !cu || !Cxu || !A || !B || !c || !V || !v || !K || !kff) return TRAJOPT_ERR_BAD_ARG;
+    if (n <= 0 || m <= 0 || T <= 0) return TRAJOPT_ERR_BAD_ARG;
+    if (trajopt_device_count() < 0) return TRAJOPT_ERR_NO_DEVICE;
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
+    const size_t in_counts[8] = {nn * (T + 1), (size_t)n * (T + 1), mm * (T + 1), (size_t)m * (T + 1), nm * (T + 1),
+                                 nn * T, nm * T, (size_t)n * T};
+    const double* in_host[8] = {Cxx, cx, Cuu, cu, Cxu, A, B, c};
+    const size_t out_counts[4] = {nn * (T + 1), (size_t)n * (T + 1), nm * T, (size_t)m * T};
+    double* out_host[4] = {V, v, K, kff};
+    size_t total = 1;
+    for (size_t x : in_counts) total += x;
+    for (size_t x : out_counts) total += x;
+    DevBuf buf;
+    TRAJOPT_HIP_CHECK(buf.alloc(total));
+    hipStream_t st = nullptr;
+    double* d = buf.p;
+    const double* din[8];
+    for (int i = 0; i < 8; ++i) {
+        TRAJOPT_HIP_CHECK(hipMemcpyAsync(d, in_host[i], in_counts[i] * sizeof(double), hipMemcpyHostToDevice, st));
+        din[i] = d;
+        d += in_counts[i];
+    }
+    double* dout[4];
+    for (int i = 0; i < 4; ++i) {
+        dout[i] = d;
+        d += out_counts[i];
+    }
+    int32_t* d_status = reinterpret_cast<int32_t*>(d);
+    const int rc = trajopt_riccati_backward_pass_batched(din[0], din[1], din[2], din[3], din[4], din[5], din[6], din[7],
+                                                         n, m, T, 1, TRAJOPT_LAYOUT_PROBLEM_MAJOR, dout[0], dout[1],
+                                                         dout[2], dout[3], d_status, st);
+    if (rc != TRAJOPT_OK) return rc;
+    for (int i = 0; i < 4; ++i)
+        TRAJOPT_HIP_CHECK(hipMemcpyAsync(out_host[i], dout[i], out_counts[i] * sizeof(double), hipMemcpyDeviceToHost, st));
+    int32_t s = 0;
+    TRAJOPT_HIP_CHECK(hipMemcpyAsync(&s, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TRAJOPT_HIP_CHECK(hipStreamSynchronize(st));
+    if (status) *status = s;
+    return TRAJOPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,409 @@
+// Thread-per-problem regularised Riccati backward pass for tiny state dimensions (dx <= 6).
+//
+// Row A1 of the hot path: the recursion of /root/reference/trajopt/ilqr/src/util.cpp:123-162, with the
+// lambda retry loop of /root/reference/trajopt/ilqr/ilqr.py:162-173 optionally folded in.
+//
+// Mapping: lane = problem, PROBLEM_MINOR layout, so element e of step t for 64 consecutive problems
+// is one contiguous 512-byte row: every global access of a wave is fully coalesced.  V, v and all
+// per-step temporaries live in VGPRs (all loops unroll).  The time loop is unrolled by two with two
+// named input register sets: the loads of step t-1 are issued before the arithmetic of step t, so
+// HBM latency hides under the ~250 dependent fp64 FMAs of a step.
+#include "smallmat.h"
+
+namespace trajopt {
+
+template <int N, int M>
+struct StepIn {
+    double A[N * N], B[N * M], Cxx[N * N], Cuu[M * M], Cxu[N * M], cx[N], cu[M], ur[M];
+};
+
+struct TppArgs {
+    trajopt_backward_io_t io;
+    trajopt_lambda_schedule_t sched;
+    size_t NP;
+    int T, reg, retry;
+    int dbg_same_step;  // developer knob: reload step T-1 every step (cache-resident inputs) to time the arithmetic
+};
+
+// Addressing: every access is a raw buffer load/store
+//     buffer_load_dwordx2 v[dst], v_lane8, s[rsrc], s_elem offen
+// with  rsrc  = descriptor whose base is the wave-uniform address of (step t, element 0, the wave's first
+//               problem) - rebuilt per step with two scalar adds,
+//       s_elem = e*NP*8, a loop-invariant SGPR shared by all arrays,
+//       v_lane8 = lane*8, ONE VGPR for the whole kernel.
+// The time loop therefore carries no vector address arithmetic and no 64-bit pointer registers
+// (flat global_load made hipcc keep one 64-bit induction pointer per element: +92 VGPRs at dx=4).
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* ubase) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ubase), 0, 0xffffffff, 0x00020000);
+}
+struct Lane {
+    unsigned v8;  // lane * 8
+    size_t NP;
+};
+template <int R>
+__device__ __forceinline__ void load_vec(double (&x)[R], const double* ubase, const Lane& ln) {
+    const __amdgpu_buffer_rsrc_t r = mk_rsrc(ubase);
+#pragma unroll
+    for (int e = 0; e < R; ++e)
+        x[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, ln.v8, (unsigned)(e * ln.NP * 8), 0));
+}
+template <int R>
+__device__ __forceinline__ void store_vec(double* ubase, const Lane& ln, const double (&x)[R]) {
+    const __amdgpu_buffer_rsrc_t r = mk_rsrc(ubase);
+#pragma unroll
+    for (int e = 0; e < R; ++e)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x[e]), r, ln.v8, (unsigned)(e * ln.NP * 8), 0);
+}
+
+// ubase(arr, E, t): wave-uniform pointer to element 0 of step t for the wave's first problem.
+#define UBASE(arr, E, t) ((arr) + ((size_t)(t) * (E)) * NP + p0)
+
+template <int N, int M, bool GN>
+__device__ __forceinline__ void load_step(StepIn<N, M>& s, const TppArgs& a, size_t p0, const Lane& off, int t) {
+    const size_t NP = a.NP;
+    if (a.dbg_same_step) t = a.T - 1;
+    load_vec<N * N>(s.A, UBASE(a.io.A, N * N, t), off);
+    load_vec<N * M>(s.B, UBASE(a.io.B, N * M, t), off);
+    load_vec<N * N>(s.Cxx, UBASE(a.io.Cxx, N * N, t), off);
+    load_vec<M * M>(s.Cuu, UBASE(a.io.Cuu, M * M, t), off);
+    load_vec<N * M>(s.Cxu, UBASE(a.io.Cxu, N * M, t), off);
+    load_vec<N>(s.cx, UBASE(a.io.cx, N, t), off);
+    load_vec<M>(s.cu, UBASE(a.io.cu, M, t), off);
+    if constexpr (GN) load_vec<M>(s.ur, UBASE(a.io.uref, M, t), off);
+}
+
+// One step of util.cpp:128-161.  Returns false when Quu_reg fails the PD test (util.cpp:145-148);
+// in that case Qxx..qu of this step have been stored (as the reference does) and V, v are untouched.
+template <int N, int M, bool FULL, bool GN>
+__device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N * N], double (&v)[N], double lam,
+                                         int reg, double& dV0, double& dV1, double (&gmax)[M], const TppArgs& a,
+                                         size_t p0, const Lane& off, int t) {
+    const size_t NP = a.NP;
+    (void)NP;
+    // W = V A, Z = V B
+    double W[N * N], Z[N * M];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) s = fma(V[i + N * k], in.A[k + N * j], s);
+            W[i + N * j] = s;
+        }
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) s = fma(V[i + N * k], in.B[k + N * j], s);
+            Z[i + N * j] = s;
+        }
+    // Qxx = Cxx + A^T W            (util.cpp:128)
+    double Qxx[N * N];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double s = in.Cxx[i + N * j];
+#pragma unroll
+            for (int k = 0; k < N; ++k) s = fma(in.A[k + N * i], W[k + N * j], s);
+            Qxx[i + N * j] = s;
+        }
+    // Qxu = Cxu + A^T Z (N x M) ; Qux = Qxu^T   (util.cpp:130)
+    double Qxu[N * M];
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double s = in.Cxu[i + N * j];
+#pragma unroll
+            for (int k = 0; k < N; ++k) s = fma(in.A[k + N * i], Z[k + N * j], s);
+            Qxu[i + N * j] = s;
+        }
+    // Quu = Cuu + B^T Z            (util.cpp:129)
+    double Quu[M * M];
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double s = in.Cuu[i + M * j];
+#pragma unroll
+            for (int k = 0; k < N; ++k) s = fma(in.B[k + N * i], Z[k + N * j], s);
+            Quu[i + M * j] = s;
+        }
+    // qx = cx + A^T v, qu = cu + B^T v   (util.cpp:132-133)
+    double qx[N], qu[M];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = in.cx[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k) s = fma(in.A[k + N * i], v[k], s);
+        qx[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        double s = in.cu[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k) s = fma(in.B[k + N * i], v[k], s);
+        qu[i] = s;
+    }
+    if constexpr (FULL) {
+        // Q-function blocks are stored before the PD test, like the reference (util.cpp:128-133)
+        if (a.io.Qxx) store_vec<N * N>(UBASE(a.io.Qxx, N * N, t), off, Qxx);
+        if (a.io.Quu) store_vec<M * M>(UBASE(a.io.Quu, M * M, t), off, Quu);
+        if (a.io.qx) store_vec<N>(UBASE(a.io.qx, N, t), off, qx);
+        if (a.io.qu) store_vec<M>(UBASE(a.io.qu, M, t), off, qu);
+        if (a.io.Qux) {
+            double Qux[M * N];  // Qux(j, i) = Qxu(i, j), (M x N) column-major
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < M; ++j) Qux[j + M * i] = Qxu[i + N * j];
+            store_vec<M * N>(UBASE(a.io.Qux, N * M, t), off, Qux);
+        }
+    }
+    // regularised blocks (util.cpp:135-143)
+    double Qxu_r[N * M], Quu_r[M * M];
+#pragma unroll
+    for (int k = 0; k < N * M; ++k) Qxu_r[k] = Qxu[k];
+#pragma unroll
+    for (int k = 0; k < M * M; ++k) Quu_r[k] = Quu[k];
+    if (reg == 2) {
+        // (V + lam I) B = Z + lam B
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) s = fma(in.A[k + N * i], in.B[k + N * j], s);
+                Qxu_r[i + N * j] = fma(lam, s, Qxu[i + N * j]);
+            }
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) s = fma(in.B[k + N * i], in.B[k + N * j], s);
+                Quu_r[i + M * j] = fma(lam, s, Quu[i + M * j]);
+            }
+        }
+    } else if (reg == 1) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) Quu_r[i + M * i] += lam;
+    }
+    // PD test + gains (util.cpp:145-152)
+    double K[M * N], kff[M];  // K(j, i): M x N column-major
+    if constexpr (M == 1) {
+        const double q = Quu_r[0];
+        if (!(q - 100.0 * kEps * fabs(q) > 0.0)) return false;
+        const double nr = -1.0 / q;
+#pragma unroll
+        for (int i = 0; i < N; ++i) K[i] = nr * Qxu_r[i];
+        kff[0] = nr * qu[0];
+    } else {
+        double L[M * M];
+        if (!sympd_factor<M>(Quu_r, L)) return false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double col[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) col[j] = Qxu_r[i + N * j];
+            chol_solve<M>(L, col);
+#pragma unroll
+            for (int j = 0; j < M; ++j) K[j + M * i] = -col[j];
+        }
+        double r[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) r[j] = qu[j];
+        chol_solve<M>(L, r);
+#pragma unroll
+        for (int j = 0; j < M; ++j) kff[j] = -r[j];
+    }
+    // Quu kff, Quu K (unregularised Quu: util.cpp:154-160)
+    double Qk[M], QK[M * N];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) s = fma(Quu[i + M * k], kff[k], s);
+        Qk[i] = s;
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) s = fma(Quu[i + M * k], K[k + M * c], s);
+            QK[i + M * c] = s;
+        }
+    // dV += [kff^T qu, 1/2 kff^T Quu kff]   (util.cpp:154)
+    {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            s0 = fma(kff[j], qu[j], s0);
+            s1 = fma(kff[j], Qk[j], s1);
+        }
+        dV0 += s0;
+        dV1 += 0.5 * s1;
+    }
+    // v = qx + K^T Quu kff + K^T qu + Qux^T kff   (util.cpp:156-157)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = qx[i];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            s = fma(K[j + M * i], Qk[j] + qu[j], s);
+            s = fma(Qxu[i + N * j], kff[j], s);
+        }
+        v[i] = s;
+    }
+    // V = Qxx + K^T Quu K + K^T Qux + Qux^T K, then symmetrise   (util.cpp:159-161)
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double s = Qxx[i + N * j];
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                s = fma(K[k + M * i], QK[k + M * j] + Qxu[j + N * k], s);
+                s = fma(Qxu[i + N * k], K[k + M * j], s);
+            }
+            W[i + N * j] = s;  // reuse W as the unsymmetrised V
+        }
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < N; ++i) V[i + N * j] = 0.5 * (W[i + N * j] + W[j + N * i]);
+
+    // stores
+    store_vec<M * N>(UBASE(a.io.K, N * M, t), off, K);
+    store_vec<M>(UBASE(a.io.kff, M, t), off, kff);
+    if constexpr (FULL) {
+        if (a.io.V) store_vec<N * N>(UBASE(a.io.V, N * N, t), off, V);
+        if (a.io.v) store_vec<N>(UBASE(a.io.v, N, t), off, v);
+    }
+    if constexpr (GN) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) gmax[j] = nanmax(gmax[j], fabs(kff[j]) / (fabs(in.ur[j]) + 1.0));
+    }
+    return true;
+}
+
+template <int N, int M, bool FULL, bool GN>
+__global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
+    const size_t p0 = (size_t)blockIdx.x * 64;  // wave-uniform: first problem of this wave
+    const unsigned lane = threadIdx.x;
+    const size_t p = p0 + lane;
+    if (p >= a.NP) return;
+    if (a.io.active && a.io.active[p] == 0) return;
+    const size_t NP = a.NP;
+    const int T = a.T;
+    const Lane off{lane * 8u, NP};  // host guarantees N*N*NP*8 + 512 < 2^32
+    double lam = a.io.lmbda[p];
+    double dlam = (a.retry && a.io.dlmbda) ? a.io.dlmbda[p] : 1.0;
+    int div = -1;
+    double dV0 = 0.0, dV1 = 0.0;
+    double gmax[M];
+
+    for (;;) {
+        div = -1;
+        dV0 = 0.0;
+        dV1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) gmax[j] = -INFINITY;
+        double V[N * N], v[N];
+        {
+            // terminal condition (util.cpp:123-124)
+            load_vec<N * N>(V, UBASE(a.io.Cxx, N * N, T), off);
+            load_vec<N>(v, UBASE(a.io.cx, N, T), off);
+            if constexpr (FULL) {
+                if (a.io.V) store_vec<N * N>(UBASE(a.io.V, N * N, T), off, V);
+                if (a.io.v) store_vec<N>(UBASE(a.io.v, N, T), off, v);
+            }
+        }
+        StepIn<N, M> s0, s1;
+        int t = T - 1;
+        if (t >= 0) load_step<N, M, GN>(s0, a, p0, off, t);
+        while (t >= 0) {
+            if (t >= 1) load_step<N, M, GN>(s1, a, p0, off, t - 1);
+            if (!bwd_step<N, M, FULL, GN>(s0, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, t)) {
+                div = t;
+                break;
+            }
+            --t;
+            if (t < 0) break;
+            if (t >= 1) load_step<N, M, GN>(s0, a, p0, off, t - 1);
+            if (!bwd_step<N, M, FULL, GN>(s1, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, t)) {
+                div = t;
+                break;
+            }
+            --t;
+        }
+        if (div < 0 || !a.retry) break;
+        // ilqr.py:166-169
+        dlam = fmax(dlam * a.sched.mult_lmbda, a.sched.mult_lmbda);
+        lam = fmax(lam * dlam, a.sched.min_lmbda);
+        if (lam > a.sched.max_lmbda) break;
+    }
+    a.io.diverge[p] = div;
+    a.io.dV[p] = dV0;
+    a.io.dV[NP + p] = dV1;
+    if (a.retry) {
+        a.io.lmbda[p] = lam;
+        if (a.io.dlmbda) a.io.dlmbda[p] = dlam;
+    }
+    if constexpr (GN) {
+        if (a.io.g_norm) {
+            double g = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) g += gmax[j];
+            a.io.g_norm[p] = g / M;
+        }
+    }
+}
+
+int g_tpp_dbg_same_step = 0;
+
+template <int N, int M>
+static int launch_nm(const TppArgs& a, hipStream_t st) {
+    const bool full = a.io.Qxx || a.io.Qux || a.io.Quu || a.io.qx || a.io.qu || a.io.V || a.io.v;
+    const bool gn = a.io.uref != nullptr && a.io.g_norm != nullptr;
+    const dim3 block(64);
+    const dim3 grid((unsigned)((a.NP + 63) / 64));
+    if (full) {
+        if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, false>), grid, block, 0, st, a);
+    } else {
+        if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, false>), grid, block, 0, st, a);
+    }
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+int launch_backward_tpp(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int retry,
+                        const trajopt_lambda_schedule_t& sched, hipStream_t st, bool* handled) {
+    TppArgs a;
+    a.io = io;
+    a.sched = sched;
+    a.NP = (size_t)NP;
+    a.T = T;
+    a.reg = reg;
+    a.retry = retry;
+    a.dbg_same_step = g_tpp_dbg_same_step;
+    *handled = true;
+    if (n == 2 && m == 1) return launch_nm<2, 1>(a, st);
+    if (n == 3 && m == 1) return launch_nm<3, 1>(a, st);
+    if (n == 4 && m == 1) return launch_nm<4, 1>(a, st);
+    if (n == 4 && m == 2) return launch_nm<4, 2>(a, st);
+    if (n == 6 && m == 1) return launch_nm<6, 1>(a, st);
+    *handled = false;
+    return TRAJOPT_OK;
+}
+
+}  // namespace trajopt

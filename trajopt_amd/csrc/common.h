@@ -1,0 +1,41 @@
+// Shared host/device helpers of the HIP library.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/trajopt_amd.h"
+
+namespace trajopt {
+
+// last HIP error text, for trajopt_last_hip_error()
+void set_hip_error(hipError_t e, const char* where);
+
+#define TRAJOPT_HIP_CHECK(expr)                                  \
+    do {                                                         \
+        hipError_t e__ = (expr);                                 \
+        if (e__ != hipSuccess) {                                 \
+            ::trajopt::set_hip_error(e__, #expr);                \
+            return TRAJOPT_ERR_HIP;                              \
+        }                                                        \
+    } while (0)
+
+// Offsets of element e (column-major, time slowest: e = i + rows*j + rows*cols*t) of problem p.
+// PROBLEM_MINOR: e*NP + p.  PROBLEM_MAJOR: p*E + e  (E = elements per problem).
+template <bool MINOR>
+__host__ __device__ inline size_t elem_off(size_t e, size_t p, size_t NP, size_t E) {
+    return MINOR ? e * NP + p : p * E + e;
+}
+
+constexpr double kEps = 2.220446049250313e-16;
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Kernel launchers implemented per translation unit (all return TRAJOPT_* codes).
+int launch_backward_tpp(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int retry,
+                        const trajopt_lambda_schedule_t& sched, hipStream_t st, bool* handled);
+int launch_backward_wg(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int layout,
+                       int retry, const trajopt_lambda_schedule_t& sched, hipStream_t st);
+int launch_riccati_wg(const double* Cxx, const double* cx, const double* Cuu, const double* cu, const double* Cxu,
+                      const double* A, const double* B, const double* c, int n, int m, int T, int64_t NP,
+                      int layout, double* V, double* v, double* K, double* kff, int32_t* status, hipStream_t st);
+
+}  // namespace trajopt

@@ -1,0 +1,248 @@
+// Batched iLQR driver (row A6): the per-problem control flow of iLQR.run,
+// /root/reference/trajopt/ilqr/ilqr.py:136-237, kept entirely on the device.
+//
+// An iteration is seven launches on one stream and no host synchronisation:
+//   prep -> quadratise -> backward pass (lambda retries inside the kernel, ilqr.py:162-173)
+//        -> gradient-norm stop (ilqr.py:176-180) -> rollout of every alpha at once (ilqr.py:187-191)
+//        -> first-accept selection + lambda update + stopping rules (ilqr.py:193-231) -> commit.
+// Problems that have stopped keep their slot and are masked out through `active`.
+// Everything is PROBLEM_MINOR.
+#include "sys.h"
+
+namespace trajopt {
+
+int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, const double* x0, const double* K,
+                   const double* kff, const double* xref, const double* uref, const double* weighting,
+                   const double* alphas_host, int nb_alphas, const int32_t* active, double* state, double* action,
+                   double* cost, double* ret, int32_t* finite, hipStream_t st);
+int launch_quadratize(const trajopt_env_t* env, int T, int64_t NP, int layout, int convention, const double* xref,
+                      const double* uref, const double* weighting, const int32_t* active, double* A, double* B,
+                      double* c, double* Cxx, double* cx, double* Cuu, double* cu, double* Cxu, hipStream_t st);
+
+struct DrvArgs {
+    trajopt_ilqr_options_t opt;
+    trajopt_ilqr_workspace_t ws;
+    int n, m;
+};
+
+__device__ __forceinline__ void grow_lambda(double& lam, double& dlam, const trajopt_lambda_schedule_t& s) {
+    dlam = fmax(dlam * s.mult_lmbda, s.mult_lmbda);  // ilqr.py:166 / :226
+    lam = fmax(lam * dlam, s.min_lmbda);             // ilqr.py:167 / :227
+}
+__device__ __forceinline__ void shrink_lambda(double& lam, double& dlam, const trajopt_lambda_schedule_t& s) {
+    dlam = fmin(dlam / s.mult_lmbda, 1.0 / s.mult_lmbda);  // ilqr.py:178 / :207
+    lam = lam * dlam * (lam > s.min_lmbda ? 1.0 : 0.0);    // ilqr.py:179 / :208
+}
+
+// ilqr.py:139-149: first alpha whose whole state trajectory is < 1e8 becomes the reference.
+__global__ void init_select_kernel(DrvArgs a) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t NP = (size_t)a.ws.nb_problems;
+    if (p >= NP) return;
+    int sel = -1;
+    for (int k = 0; k < a.opt.nb_alphas; ++k)
+        if (a.ws.cand_finite[(size_t)k * NP + p]) { sel = k; break; }
+    a.ws.sel[p] = sel;
+    const double r = sel >= 0 ? a.ws.cand_ret[(size_t)sel * NP + p] : -INFINITY;  // ilqr.py:87
+    a.ws.last_return[p] = r;
+    a.ws.trace[p] = r;  // ilqr.py:149
+    a.ws.trace_len[p] = 1;
+    a.ws.status[p] = 0;
+    a.ws.iters[p] = 0;
+}
+
+__global__ void prep_kernel(DrvArgs a) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)a.ws.nb_problems) return;
+    const int act = a.ws.status[p] == 0 ? 1 : 0;
+    a.ws.active[p] = act;
+    if (act) a.ws.iters[p] += 1;
+}
+
+// ilqr.py:175-180 plus the "backward pass gave up" path (:168 -> :224-231).
+__global__ void post_backward_kernel(DrvArgs a) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)a.ws.nb_problems) return;
+    if (!a.ws.active[p]) return;
+    double lam = a.ws.lmbda[p], dlam = a.ws.dlmbda[p];
+    const double g = a.ws.g_norm[p];
+    if (g < a.opt.tolgrad && lam < 1e-5) {
+        shrink_lambda(lam, dlam, a.opt.sched);
+        a.ws.status[p] = 1;
+        a.ws.active[p] = 0;
+    } else if (a.ws.diverge[p] >= 0) {
+        grow_lambda(lam, dlam, a.opt.sched);
+        if (lam > a.opt.sched.max_lmbda) a.ws.status[p] = 3;
+        a.ws.active[p] = 0;
+    }
+    a.ws.lmbda[p] = lam;
+    a.ws.dlmbda[p] = dlam;
+}
+
+// ilqr.py:187-231: sequential first-accept over the alphas, evaluated from the precomputed returns.
+__global__ void select_kernel(DrvArgs a) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t NP = (size_t)a.ws.nb_problems;
+    if (p >= NP) return;
+    a.ws.sel[p] = -1;
+    if (!a.ws.active[p]) return;
+    const double last = a.ws.last_return[p];
+    const double dV0 = a.ws.dV[p], dV1 = a.ws.dV[NP + p];
+    int sel = -1;
+    double best = 0.0, dret_sel = 0.0, alpha_last = a.ws.alpha[p];
+    for (int k = 0; k < a.opt.nb_alphas; ++k) {
+        const double alpha = a.opt.alphas[k];
+        const double ret = a.ws.cand_ret[(size_t)k * NP + p];
+        const double dret = last - ret;
+        const double expected = -1.0 * alpha * (dV0 + alpha * dV1);
+        const double imp = dret / expected;
+        if (sel < 0) alpha_last = alpha;  // self.alpha follows the loop variable (ilqr.py:188)
+        if (imp >= a.opt.min_imp) {       // NaN compares false -> rejected
+            if (!a.opt.argmin_alpha) { sel = k; dret_sel = dret; break; }
+            if (sel < 0 || ret < best) { sel = k; best = ret; dret_sel = dret; alpha_last = alpha; }
+        }
+    }
+    double lam = a.ws.lmbda[p], dlam = a.ws.dlmbda[p];
+    if (sel >= 0) {
+        shrink_lambda(lam, dlam, a.opt.sched);
+        const double ret = a.ws.cand_ret[(size_t)sel * NP + p];
+        a.ws.last_return[p] = ret;
+        const int len = a.ws.trace_len[p];
+        if (len < a.ws.trace_cap) {
+            a.ws.trace[(size_t)len * NP + p] = ret;  // ilqr.py:219
+            a.ws.trace_len[p] = len + 1;
+        }
+        if (dret_sel < a.opt.tolfun) a.ws.status[p] = 2;  // ilqr.py:222
+        a.ws.sel[p] = sel;
+    } else {
+        grow_lambda(lam, dlam, a.opt.sched);
+        if (lam > a.opt.sched.max_lmbda) a.ws.status[p] = 3;  // ilqr.py:228
+    }
+    a.ws.alpha[p] = alpha_last;
+    a.ws.lmbda[p] = lam;
+    a.ws.dlmbda[p] = dlam;
+}
+
+// Copy the accepted candidate into the reference slots (ilqr.py:210-217 / :142-143).  Thread per
+// (problem, step); `with_ctl` also promotes the candidate gains (and value functions if kept).
+__global__ void commit_kernel(DrvArgs a, int with_ctl) {
+    const size_t NP = (size_t)a.ws.nb_problems;
+    const int T = a.ws.nb_steps, n = a.n, m = a.m;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NP * (size_t)(T + 1)) return;
+    const int t = (int)(idx / NP);
+    const size_t p = idx % NP;
+    const int sel = a.ws.sel[p];
+    if (sel < 0) return;
+    const double* st = a.ws.cand_state + (size_t)sel * (size_t)n * (T + 1) * NP;
+    for (int i = 0; i < n; ++i) a.ws.xref[((size_t)n * t + i) * NP + p] = st[((size_t)n * t + i) * NP + p];
+    if (t < T) {
+        const double* ac = a.ws.cand_action + (size_t)sel * (size_t)m * T * NP;
+        for (int j = 0; j < m; ++j) a.ws.uref[((size_t)m * t + j) * NP + p] = ac[((size_t)m * t + j) * NP + p];
+    }
+    if (!with_ctl) return;
+    if (t < T) {
+        for (int k = 0; k < n * m; ++k) a.ws.K[((size_t)n * m * t + k) * NP + p] = a.ws.cand_K[((size_t)n * m * t + k) * NP + p];
+        for (int j = 0; j < m; ++j) a.ws.kff[((size_t)m * t + j) * NP + p] = a.ws.cand_kff[((size_t)m * t + j) * NP + p];
+    }
+    if (a.opt.keep_value) {
+        for (int k = 0; k < n * n; ++k) a.ws.V[((size_t)n * n * t + k) * NP + p] = a.ws.cand_V[((size_t)n * n * t + k) * NP + p];
+        for (int i = 0; i < n; ++i) a.ws.v[((size_t)n * t + i) * NP + p] = a.ws.cand_v[((size_t)n * t + i) * NP + p];
+        if (t < T) {
+            for (int k = 0; k < n * n; ++k) a.ws.Qxx[((size_t)n * n * t + k) * NP + p] = a.ws.cand_Qxx[((size_t)n * n * t + k) * NP + p];
+            for (int k = 0; k < n * m; ++k) a.ws.Qux[((size_t)n * m * t + k) * NP + p] = a.ws.cand_Qux[((size_t)n * m * t + k) * NP + p];
+            for (int k = 0; k < m * m; ++k) a.ws.Quu[((size_t)m * m * t + k) * NP + p] = a.ws.cand_Quu[((size_t)m * m * t + k) * NP + p];
+            for (int i = 0; i < n; ++i) a.ws.qx[((size_t)n * t + i) * NP + p] = a.ws.cand_qx[((size_t)n * t + i) * NP + p];
+            for (int j = 0; j < m; ++j) a.ws.qu[((size_t)m * t + j) * NP + p] = a.ws.cand_qu[((size_t)m * t + j) * NP + p];
+        }
+    }
+}
+
+static int check_ws(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt, const trajopt_ilqr_workspace_t* ws) {
+    if (!env || !opt || !ws) return TRAJOPT_ERR_BAD_ARG;
+    if (ws->nb_steps <= 0 || ws->nb_problems <= 0 || opt->nb_alphas <= 0 || opt->nb_alphas > TRAJOPT_MAX_ALPHAS)
+        return TRAJOPT_ERR_BAD_ARG;
+    const void* need[] = {ws->x0, ws->weighting, ws->xref, ws->uref, ws->K, ws->kff, ws->last_return, ws->lmbda,
+                          ws->dlmbda, ws->alpha, ws->status, ws->iters, ws->trace_len, ws->trace, ws->A, ws->B,
+                          ws->Cxx, ws->cx, ws->Cuu, ws->cu, ws->Cxu, ws->cand_K, ws->cand_kff, ws->dV, ws->g_norm,
+                          ws->diverge, ws->active, ws->sel, ws->cand_state, ws->cand_action, ws->cand_ret,
+                          ws->cand_finite};
+    for (const void* q : need)
+        if (!q) return TRAJOPT_ERR_BAD_ARG;
+    if (opt->keep_value) {
+        const void* need2[] = {ws->V, ws->v, ws->Qxx, ws->Qux, ws->Quu, ws->qx, ws->qu, ws->cand_V, ws->cand_v,
+                               ws->cand_Qxx, ws->cand_Qux, ws->cand_Quu, ws->cand_qx, ws->cand_qu};
+        for (const void* q : need2)
+            if (!q) return TRAJOPT_ERR_BAD_ARG;
+    }
+    if (ws->trace_cap < 1) return TRAJOPT_ERR_BAD_ARG;
+    return TRAJOPT_OK;
+}
+
+}  // namespace trajopt
+
+using namespace trajopt;
+
+extern "C" {
+
+int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
+                              const trajopt_ilqr_workspace_t* ws, void* stream) {
+    int rc = check_ws(env, opt, ws);
+    if (rc != TRAJOPT_OK) return rc;
+    hipStream_t st = as_stream(stream);
+    const int64_t NP = ws->nb_problems;
+    const int T = ws->nb_steps;
+    rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->K, ws->kff, ws->xref, ws->uref,
+                        ws->weighting, opt->alphas, opt->nb_alphas, nullptr, ws->cand_state, ws->cand_action, nullptr,
+                        ws->cand_ret, ws->cand_finite, st);
+    if (rc != TRAJOPT_OK) return rc;
+    DrvArgs a{*opt, *ws, env->dm_state, env->dm_act};
+    const unsigned g1 = (unsigned)((NP + 255) / 256);
+    hipLaunchKernelGGL(init_select_kernel, dim3(g1), dim3(256), 0, st, a);
+    const size_t tot = (size_t)NP * (T + 1);
+    hipLaunchKernelGGL(commit_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, 0);
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
+                         const trajopt_ilqr_workspace_t* ws, int nb_iter, void* stream) {
+    int rc = check_ws(env, opt, ws);
+    if (rc != TRAJOPT_OK) return rc;
+    hipStream_t st = as_stream(stream);
+    const int64_t NP = ws->nb_problems;
+    const int T = ws->nb_steps, n = env->dm_state, m = env->dm_act;
+    DrvArgs a{*opt, *ws, n, m};
+    const unsigned g1 = (unsigned)((NP + 255) / 256);
+    const size_t tot = (size_t)NP * (T + 1);
+    const unsigned g2 = (unsigned)((tot + 255) / 256);
+    trajopt_backward_io_t io{};
+    io.Cxx = ws->Cxx; io.cx = ws->cx; io.Cuu = ws->Cuu; io.cu = ws->cu; io.Cxu = ws->Cxu; io.A = ws->A; io.B = ws->B;
+    io.lmbda = ws->lmbda; io.dlmbda = ws->dlmbda;
+    if (opt->keep_value) {
+        io.Qxx = ws->cand_Qxx; io.Qux = ws->cand_Qux; io.Quu = ws->cand_Quu; io.qx = ws->cand_qx; io.qu = ws->cand_qu;
+        io.V = ws->cand_V; io.v = ws->cand_v;
+    }
+    io.dV = ws->dV; io.K = ws->cand_K; io.kff = ws->cand_kff; io.diverge = ws->diverge;
+    io.uref = ws->uref; io.g_norm = ws->g_norm; io.active = ws->active;
+    for (int it = 0; it < nb_iter; ++it) {
+        hipLaunchKernelGGL(prep_kernel, dim3(g1), dim3(256), 0, st, a);
+        rc = launch_quadratize(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 0, ws->xref, ws->uref, ws->weighting,
+                               ws->active, ws->A, ws->B, nullptr, ws->Cxx, ws->cx, ws->Cuu, ws->cu, ws->Cxu, st);
+        if (rc != TRAJOPT_OK) return rc;
+        rc = trajopt_ilqr_backward_pass_batched(&io, opt->reg, n, m, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 1,
+                                                &opt->sched, st);
+        if (rc != TRAJOPT_OK) return rc;
+        hipLaunchKernelGGL(post_backward_kernel, dim3(g1), dim3(256), 0, st, a);
+        rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
+                            ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
+                            ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st);
+        if (rc != TRAJOPT_OK) return rc;
+        hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(commit_kernel, dim3(g2), dim3(256), 0, st, a, 1);
+    }
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+// Device-side env models (row A8): dynamics and cost of the envs the configs name, written for the GPU.
+//
+//   pendulum         /root/reference/trajopt/envs/pendulum/pendulum.py:58-76, :111-125
+//   cartpole         /root/reference/trajopt/envs/cartpole/cartpole.py:62-97, :112-127
+//   double cartpole  /root/reference/trajopt/envs/double_cartpole/double_cartpole.py:61-155, :170-187
+//   LQR (affine LTI) /root/reference/trajopt/envs/lqr/lqr_v0.py:50-66, :89-94
+//   quadrotor        build-defined 12-state rigid body (no counterpart in the reference)
+//
+// Everything is a template over the scalar type so the same vector field serves the rollout (double)
+// and the quadratisation (Dual<K>: forward-mode AD carrying K tangent directions, which reproduces
+// autograd's jacobian() of the discrete RK4+clip map to round-off; objects.py:108-117).
+// phys[] per model:  pendulum {g, m, l, k}; cartpole {g, Mc, Mp, l, fr};
+//                    double cartpole {g, Mc, Mp1, Mp2, L1, L2}; quadrotor {g, mass, L, Ixx, Iyy, Izz, kM}.
+#pragma once
+#include "common.h"
+
+namespace trajopt {
+
+template <int K>
+struct Dual {
+    double v;
+    double d[K];
+};
+
+// ---- scalar-generic arithmetic ------------------------------------------------------------------
+__device__ __forceinline__ double dmake(double x) { return x; }
+template <int K> __device__ __forceinline__ Dual<K> constant(double x) {
+    Dual<K> r; r.v = x;
+#pragma unroll
+    for (int k = 0; k < K; ++k) r.d[k] = 0.0;
+    return r;
+}
+template <class X> struct Scalar;
+template <> struct Scalar<double> {
+    static __device__ __forceinline__ double c(double x) { return x; }
+    static __device__ __forceinline__ double val(double x) { return x; }
+};
+template <int K> struct Scalar<Dual<K>> {
+    static __device__ __forceinline__ Dual<K> c(double x) { return constant<K>(x); }
+    static __device__ __forceinline__ double val(const Dual<K>& x) { return x.v; }
+};
+
+#define TJ_DUAL_BINOP(OP, VEXPR, DEXPR)                                                                      \
+    template <int K> __device__ __forceinline__ Dual<K> operator OP(const Dual<K>& a, const Dual<K>& b) {    \
+        Dual<K> r; r.v = VEXPR;                                                                              \
+        _Pragma("unroll") for (int k = 0; k < K; ++k) r.d[k] = DEXPR;                                        \
+        return r;                                                                                            \
+    }
+TJ_DUAL_BINOP(+, a.v + b.v, a.d[k] + b.d[k])
+TJ_DUAL_BINOP(-, a.v - b.v, a.d[k] - b.d[k])
+TJ_DUAL_BINOP(*, a.v * b.v, fma(a.d[k], b.v, a.v * b.d[k]))
+#undef TJ_DUAL_BINOP
+template <int K> __device__ __forceinline__ Dual<K> operator/(const Dual<K>& a, const Dual<K>& b) {
+    Dual<K> r; const double ib = 1.0 / b.v; r.v = a.v * ib;
+#pragma unroll
+    for (int k = 0; k < K; ++k) r.d[k] = (a.d[k] - r.v * b.d[k]) * ib;
+    return r;
+}
+template <int K> __device__ __forceinline__ Dual<K> operator-(const Dual<K>& a) {
+    Dual<K> r; r.v = -a.v;
+#pragma unroll
+    for (int k = 0; k < K; ++k) r.d[k] = -a.d[k];
+    return r;
+}
+template <int K> __device__ __forceinline__ Dual<K> operator+(const Dual<K>& a, double b) { Dual<K> r = a; r.v += b; return r; }
+template <int K> __device__ __forceinline__ Dual<K> operator+(double b, const Dual<K>& a) { Dual<K> r = a; r.v += b; return r; }
+template <int K> __device__ __forceinline__ Dual<K> operator-(const Dual<K>& a, double b) { Dual<K> r = a; r.v -= b; return r; }
+template <int K> __device__ __forceinline__ Dual<K> operator-(double b, const Dual<K>& a) { Dual<K> r = -a; r.v += b; return r; }
+template <int K> __device__ __forceinline__ Dual<K> operator*(const Dual<K>& a, double b) {
+    Dual<K> r; r.v = a.v * b;
+#pragma unroll
+    for (int k = 0; k < K; ++k) r.d[k] = a.d[k] * b;
+    return r;
+}
+template <int K> __device__ __forceinline__ Dual<K> operator*(double b, const Dual<K>& a) { return a * b; }
+template <int K> __device__ __forceinline__ Dual<K> operator/(const Dual<K>& a, double b) { return a * (1.0 / b); }
+
+// sin and cos together (one range reduction)
+__device__ __forceinline__ void sincos_g(double x, double& s, double& c) { sincos(x, &s, &c); }
+template <int K> __device__ __forceinline__ void sincos_g(const Dual<K>& x, Dual<K>& s, Dual<K>& c) {
+    double sv, cv;
+    sincos(x.v, &sv, &cv);
+    s.v = sv; c.v = cv;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { s.d[k] = cv * x.d[k]; c.d[k] = -sv * x.d[k]; }
+}
+
+// np.clip(x, -lim, lim); derivative follows autograd: g * (ans != a_min) * (ans != a_max)
+__device__ __forceinline__ double clip_g(double x, double lim) { return fmin(fmax(x, -lim), lim); }
+template <int K> __device__ __forceinline__ Dual<K> clip_g(const Dual<K>& x, double lim) {
+    Dual<K> r; r.v = fmin(fmax(x.v, -lim), lim);
+    const double mask = (r.v != -lim && r.v != lim) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) r.d[k] = mask * x.d[k];
+    return r;
+}
+
+// ---- vector fields --------------------------------------------------------------------------------
+template <int MODEL> struct Model;
+
+template <> struct Model<TRAJOPT_ENV_PENDULUM> {
+    static constexpr int N = 2, M = 1;
+    template <class X> static __device__ __forceinline__ void f(const trajopt_env_t& e, const X (&x)[N], const X (&u)[M], X (&dx)[N]) {
+        const double g = e.phys[0], m = e.phys[1], l = e.phys[2], k = e.phys[3];
+        X s, c;
+        sincos_g(x[0] + M_PI, s, c);
+        dx[0] = x[1];
+        dx[1] = (-3.0 * g / (2.0 * l)) * s + (3.0 / (m * l * l)) * (u[0] - k * x[1]);
+    }
+};
+
+template <> struct Model<TRAJOPT_ENV_CARTPOLE> {
+    static constexpr int N = 4, M = 1;
+    template <class X> static __device__ __forceinline__ void f(const trajopt_env_t& e, const X (&x)[N], const X (&u)[M], X (&dx)[N]) {
+        const double g = e.phys[0], Mc = e.phys[1], Mp = e.phys[2], l = e.phys[3], fr = e.phys[4];
+        const double Mt = Mc + Mp;
+        X sth, cth;
+        sincos_g(x[1], sth, cth);
+        const X dq = x[2], dth = x[3];
+        const X dth2s = dth * dth * sth;
+        const X num = g * sth + cth * (-(u[0] - fr * dq) - (Mp * l) * dth2s) / Mt;
+        const X den = l * ((4.0 / 3.0) - Mp * cth * cth / Mt);
+        const X ddth = num / den;
+        dx[0] = dq;
+        dx[1] = dth;
+        dx[2] = (u[0] + (Mp * l) * (dth2s - ddth * cth)) / Mt;
+        dx[3] = ddth;
+    }
+};
+
+template <> struct Model<TRAJOPT_ENV_DOUBLE_CARTPOLE> {
+    static constexpr int N = 6, M = 1;
+    template <class X> static __device__ __forceinline__ void f(const trajopt_env_t& e, const X (&x)[N], const X (&u)[M], X (&dx)[N]) {
+        const double g = e.phys[0], Mc = e.phys[1], Mp1 = e.phys[2], Mp2 = e.phys[3], L1 = e.phys[4], L2 = e.phys[5];
+        const double Mt = Mc + Mp1 + Mp2, l1 = 0.5 * L1, l2 = 0.5 * L2, J1 = Mp1 * L1 / 12.0, J2 = Mp2 * L2 / 12.0;
+        const double a = Mp1 * l1 + Mp2 * L2, b = Mp2 * l2, d = L1 * l2 * Mp2;
+        const double m22 = l1 * l1 * Mp1 + L1 * L1 * Mp2 + J1, m33 = l2 * l2 * Mp2 + J2;
+        X s1, c1, s2, c2, sd, cd;
+        sincos_g(x[1], s1, c1);
+        sincos_g(x[2], s2, c2);
+        sincos_g(x[1] - x[2], sd, cd);
+        const X dth1 = x[4], dth2 = x[5];
+        // symmetric inertia matrix  [[Mt, m12, m13], [m12, m22, m23], [m13, m23, m33]]
+        const X m12 = a * c1, m13 = b * c2, m23 = d * cd;
+        // rhs = [u, 0, 0] - C dq - G
+        const X r0 = u[0] + (a * dth1) * dth1 * s1 + (b * dth2) * dth2 * s2;
+        const X r1 = (a - Mp2 * L2 + Mp2 * L1) * g * s1 - (d * dth2) * dth2 * sd;   // -(C23 dth2) - G2
+        const X r2 = (b * g) * s2 + (d * dth1) * dth1 * sd;                          // -(C32 dth1) - G3
+        // solve M dd = r by symmetric elimination (M is SPD: a mass matrix); no pivoting needed
+        const double i11 = 1.0 / Mt;                    // Mt is a constant
+        const X l21 = m12 * i11, l31 = m13 * i11;
+        const X a22 = m22 - l21 * m12, a23 = m23 - l21 * m13, a33 = m33 - l31 * m13;
+        const X b1 = r1 - l21 * r0, b2 = r2 - l31 * r0;
+        const X l32 = a23 / a22;
+        const X c33 = a33 - l32 * a23;
+        const X y2 = (b2 - l32 * b1) / c33;
+        const X y1 = (b1 - a23 * y2) / a22;
+        const X y0 = (r0 - m12 * y1 - m13 * y2) * i11;
+        dx[0] = x[3]; dx[1] = dth1; dx[2] = dth2; dx[3] = y0; dx[4] = y1; dx[5] = y2;
+    }
+};
+
+template <> struct Model<TRAJOPT_ENV_QUADROTOR> {
+    static constexpr int N = 12, M = 4;
+    template <class X> static __device__ __forceinline__ void f(const trajopt_env_t& e, const X (&x)[N], const X (&u)[M], X (&dx)[N]) {
+        const double g = e.phys[0], im = 1.0 / e.phys[1], L = e.phys[2], Ixx = e.phys[3], Iyy = e.phys[4], Izz = e.phys[5],
+                     kM = e.phys[6];
+        X sph, cph, sth, cth, sps, cps;
+        sincos_g(x[3], sph, cph);
+        sincos_g(x[4], sth, cth);
+        sincos_g(x[5], sps, cps);
+        const X p = x[9], q = x[10], r = x[11];
+        const X F = (u[0] + u[1] + u[2] + u[3]) * im;
+        const X tth = sth / cth;
+        const X sq_cr = sph * q + cph * r;
+        dx[0] = x[6]; dx[1] = x[7]; dx[2] = x[8];
+        dx[3] = p + tth * sq_cr;
+        dx[4] = cph * q - sph * r;
+        dx[5] = sq_cr / cth;
+        dx[6] = (cph * sth * cps + sph * sps) * F;
+        dx[7] = (cph * sth * sps - sph * cps) * F;
+        dx[8] = cph * cth * F - g;
+        dx[9] = (L * (u[1] - u[3]) - (Izz - Iyy) * q * r) / Ixx;
+        dx[10] = (L * (u[2] - u[0]) - (Ixx - Izz) * p * r) / Iyy;
+        dx[11] = (kM * (u[0] - u[1] + u[2] - u[3]) - (Iyy - Ixx) * p * q) / Izz;
+    }
+};
+
+// env.dynamics(x, u): clip(u) -> RK4(dt) -> clip(xn)       (cartpole.py:62-97)
+template <int MODEL, class X>
+__device__ __forceinline__ void env_dynamics(const trajopt_env_t& e, const X (&x)[Model<MODEL>::N],
+                                             const X (&u)[Model<MODEL>::M], X (&xn)[Model<MODEL>::N]) {
+    constexpr int N = Model<MODEL>::N, M = Model<MODEL>::M;
+    X uc[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) uc[j] = clip_g(u[j], e.umax[j]);
+    const double dt = e.dt;
+    X k1[N], k2[N], k3[N], k4[N], y[N];
+    Model<MODEL>::f(e, x, uc, k1);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = x[i] + (0.5 * dt) * k1[i];
+    Model<MODEL>::f(e, y, uc, k2);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = x[i] + (0.5 * dt) * k2[i];
+    Model<MODEL>::f(e, y, uc, k3);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = x[i] + dt * k3[i];
+    Model<MODEL>::f(e, y, uc, k4);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const X s = x[i] + (dt / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        xn[i] = clip_g(s, e.xmax[i]);
+    }
+}
+
+// LQR env: xn = A x + B clip(u) + c, no state clip (lqr_v0.py:50-66).  Run-time dims (<= MAX): loops
+// run to the compile-time maximum with guards so the arrays keep static indices (stay in registers).
+template <class X>
+__device__ __forceinline__ void lqr_dynamics(const trajopt_env_t& e, const X (&x)[TRAJOPT_ENV_MAX_STATE],
+                                             const X (&u)[TRAJOPT_ENV_MAX_ACT], X (&xn)[TRAJOPT_ENV_MAX_STATE]) {
+    const int n = e.dm_state, m = e.dm_act;
+    X uc[TRAJOPT_ENV_MAX_ACT];
+#pragma unroll
+    for (int j = 0; j < TRAJOPT_ENV_MAX_ACT; ++j) uc[j] = (j < m) ? clip_g(u[j], e.umax[j]) : Scalar<X>::c(0.0);
+#pragma unroll
+    for (int i = 0; i < TRAJOPT_ENV_MAX_STATE; ++i) {
+        if (i < n) {
+            X s = Scalar<X>::c(0.0), s2 = Scalar<X>::c(0.0);
+#pragma unroll
+            for (int j = 0; j < TRAJOPT_ENV_MAX_STATE; ++j)
+                if (j < n) s = s + e.lin_A[i + n * j] * x[j];
+#pragma unroll
+            for (int j = 0; j < TRAJOPT_ENV_MAX_ACT; ++j)
+                if (j < m) s2 = s2 + e.lin_B[i + n * j] * uc[j];
+            xn[i] = s + s2 + e.lin_c[i];
+        }
+    }
+}
+
+__device__ __forceinline__ double wrap_angle(double x) {  // ((x + pi) % 2pi) - pi with Python's %
+    const double two_pi = 2.0 * M_PI;
+    double r = fmod(x + M_PI, two_pi);
+    if (r < 0.0) r += two_pi;
+    return r - M_PI;
+}
+
+// env.cost(x, u, u_last, a) with identity features (cartpole.py:112-127; LQR: lqr_v0.py:89-94).
+// N, M are array capacities; n, m the live dimensions.
+template <int N, int M>
+__device__ __forceinline__ double env_cost(const trajopt_env_t& e, const double (&x)[N], const double (&u)[M],
+                                           const double (&u_last)[M], double a, int n, int m) {
+    double c = 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+        if (j < m) {
+            const double d = e.slew_rate ? (u[j] - u_last[j]) : u[j];
+            c = fma(d * e.uw[j], d, c);
+        }
+    if (a != 0.0) {  // Python `if a:` drops the state cost for an exactly-zero weight
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i < n) {
+                const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
+                const double r = y - e.goal[i];
+                s = fma(r * e.gw[i], r, s);
+            }
+        c = fma(a, s, c);
+    }
+    return e.cost_times_dt ? e.dt * c : c;
+}
+
+}  // namespace trajopt

@@ -1,0 +1,223 @@
+// Forward rollouts (row A3) and single env steps (row A8).
+//
+//   iLQR.forward_pass     /root/reference/trajopt/ilqr/ilqr.py:89-102
+//   LinearControl.action  /root/reference/trajopt/ilqr/objects.py:137-139
+//   env.dynamics / cost   /root/reference/trajopt/envs/cartpole/cartpole.py:62-97,112-127 (and siblings)
+//
+// One thread integrates one (problem, alpha) pair over the whole horizon; the thread index runs over
+// problems fastest, so in PROBLEM_MINOR layout every load of K/kff/xref/uref and every store of the
+// candidate state/action/cost is one coalesced row per wave, and the alphas of a problem re-read the
+// same gain rows from L2.  The inputs of step t+1 are fetched while step t integrates.
+#include "sys.h"
+
+namespace trajopt {
+
+struct RolloutArgs {
+    trajopt_env_t env;
+    const double *x0, *K, *kff, *xref, *uref, *weighting;
+    const int32_t* active;
+    double *state, *action, *cost, *ret;
+    int32_t* finite;
+    double alphas[TRAJOPT_MAX_ALPHAS];
+    size_t NP;
+    int T, nb_alphas;
+};
+
+template <bool MINOR>
+__device__ __forceinline__ size_t gi(size_t e_total, size_t E_total, size_t p, size_t NP) {
+    return MINOR ? e_total * NP + p : p * E_total + e_total;
+}
+
+template <class SYS, bool MINOR>
+__global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
+    constexpr int N = SYS::N, M = SYS::M;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t NP = a.NP;
+    if (idx >= NP * (size_t)a.nb_alphas) return;
+    const size_t p = idx % NP;
+    const int ai = (int)(idx / NP);
+    if (a.active && a.active[p] == 0) return;
+    const trajopt_env_t& e = a.env;
+    const int n = SYS::n(e), m = SYS::m(e), T = a.T;
+    const double alpha = a.alphas[ai];
+    const size_t En1 = (size_t)n * (T + 1), En = (size_t)n * T, Em = (size_t)m * T, Enm = (size_t)n * m * T;
+    // candidate planes: alpha slowest
+    double* st = a.state ? a.state + (size_t)ai * En1 * NP : nullptr;
+    double* ac = a.action ? a.action + (size_t)ai * Em * NP : nullptr;
+    double* co = a.cost ? a.cost + (size_t)ai * (size_t)(T + 1) * NP : nullptr;
+
+    double x[N], xr[N], ur[M], kf[M], Kt[M * N];
+    bool fin = true;
+    double total = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (i < n) {
+            x[i] = a.x0[gi<MINOR>(i, n, p, NP)];
+            fin = fin && (x[i] < 1e8);
+            if (st) st[gi<MINOR>(i, En1, p, NP)] = x[i];
+        }
+    auto load = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i < n) xr[i] = a.xref[gi<MINOR>((size_t)n * t + i, En1, p, NP)];
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+            if (j < m) {
+                ur[j] = a.uref[gi<MINOR>((size_t)m * t + j, Em, p, NP)];
+                kf[j] = a.kff[gi<MINOR>((size_t)m * t + j, Em, p, NP)];
+            }
+#pragma unroll
+        for (int k = 0; k < M * N; ++k)
+            if (k < n * m) Kt[k] = a.K[gi<MINOR>((size_t)n * m * t + k, Enm, p, NP)];
+    };
+    if (T > 0) load(0);
+    double w = a.weighting[0];
+    for (int t = 0; t < T; ++t) {
+        // u = clip(uref + alpha kff + K (x - xref))    objects.py:137-139, ilqr.py:97
+        double u[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+            if (j < m) {
+                double s = fma(alpha, kf[j], ur[j]);
+                double kx = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    if (i < n) kx = fma(Kt[j + m * i], x[i] - xr[i], kx);
+                u[j] = clip_g(s + kx, e.umax[j]);
+            }
+        const double wt = w;
+        if (t + 1 < T) load(t + 1);  // prefetch the next step's gains while this one integrates
+        w = a.weighting[t + 1];
+        const double c = env_cost<N, M>(e, x, u, u, wt, n, m);  // ilqr.py:98 passes u_last = u_t
+        total += c;
+        if (co) co[gi<MINOR>(t, T + 1, p, NP)] = c;
+        if (ac) {
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if (j < m) ac[gi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
+        }
+        double xn[N];
+        SYS::dynamics(e, x, u, xn);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i < n) {
+                x[i] = xn[i];
+                fin = fin && (x[i] < 1e8);
+                if (st) st[gi<MINOR>((size_t)n * (t + 1) + i, En1, p, NP)] = x[i];
+            }
+    }
+    {
+        double zero[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) zero[j] = 0.0;
+        const double c = env_cost<N, M>(e, x, zero, zero, w, n, m);  // ilqr.py:101
+        total += c;
+        if (co) co[gi<MINOR>(T, T + 1, p, NP)] = c;
+    }
+    if (a.ret) a.ret[(size_t)ai * NP + p] = total;
+    if (a.finite) a.finite[(size_t)ai * NP + p] = fin ? 1 : 0;
+}
+
+struct StepArgs {
+    trajopt_env_t env;
+    const double *x, *u, *u_last, *a;
+    double *xn, *cost;
+    size_t NP;
+};
+
+template <class SYS, bool MINOR>
+__global__ void env_step_kernel(StepArgs s) {
+    constexpr int N = SYS::N, M = SYS::M;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= s.NP) return;
+    const trajopt_env_t& e = s.env;
+    const int n = SYS::n(e), m = SYS::m(e);
+    double x[N], u[M], ul[M], xn[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = (i < n) ? s.x[gi<MINOR>(i, n, p, s.NP)] : 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        u[j] = (j < m) ? s.u[gi<MINOR>(j, m, p, s.NP)] : 0.0;
+        ul[j] = (j < m && s.u_last) ? s.u_last[gi<MINOR>(j, m, p, s.NP)] : 0.0;
+    }
+    if (s.cost) s.cost[p] = env_cost<N, M>(e, x, u, ul, s.a ? s.a[p] : 1.0, n, m);
+    if (s.xn) {
+        SYS::dynamics(e, x, u, xn);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i < n) s.xn[gi<MINOR>(i, n, p, s.NP)] = xn[i];
+    }
+}
+
+struct RolloutLaunch {
+    RolloutArgs a;
+    int layout;
+    hipStream_t st;
+    template <class SYS>
+    void operator()() {
+        const size_t total = a.NP * (size_t)a.nb_alphas;
+        const dim3 grid((unsigned)((total + 63) / 64)), block(64);
+        if (layout == TRAJOPT_LAYOUT_PROBLEM_MINOR) hipLaunchKernelGGL((rollout_kernel<SYS, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((rollout_kernel<SYS, false>), grid, block, 0, st, a);
+    }
+};
+
+struct StepLaunch {
+    StepArgs a;
+    int layout;
+    hipStream_t st;
+    template <class SYS>
+    void operator()() {
+        const dim3 grid((unsigned)((a.NP + 63) / 64)), block(64);
+        if (layout == TRAJOPT_LAYOUT_PROBLEM_MINOR) hipLaunchKernelGGL((env_step_kernel<SYS, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((env_step_kernel<SYS, false>), grid, block, 0, st, a);
+    }
+};
+
+int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, const double* x0, const double* K,
+                   const double* kff, const double* xref, const double* uref, const double* weighting,
+                   const double* alphas_host, int nb_alphas, const int32_t* active, double* state, double* action,
+                   double* cost, double* ret, int32_t* finite, hipStream_t st) {
+    RolloutLaunch L;
+    L.a.env = *env;
+    L.a.x0 = x0; L.a.K = K; L.a.kff = kff; L.a.xref = xref; L.a.uref = uref; L.a.weighting = weighting;
+    L.a.active = active; L.a.state = state; L.a.action = action; L.a.cost = cost; L.a.ret = ret; L.a.finite = finite;
+    for (int i = 0; i < TRAJOPT_MAX_ALPHAS; ++i) L.a.alphas[i] = i < nb_alphas ? alphas_host[i] : 0.0;
+    L.a.NP = (size_t)NP; L.a.T = T; L.a.nb_alphas = nb_alphas;
+    L.layout = layout; L.st = st;
+    if (!dispatch_model(*env, L)) return TRAJOPT_ERR_UNSUPPORTED;
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+}  // namespace trajopt
+
+using namespace trajopt;
+
+extern "C" {
+
+int trajopt_ilqr_forward_pass_batched(const trajopt_env_t* env, int nb_steps, int64_t nb_problems, int layout,
+                                      const double* x0, const double* K, const double* kff, const double* xref,
+                                      const double* uref, const double* weighting, const double* alphas_host,
+                                      int nb_alphas, const int32_t* active, double* state, double* action,
+                                      double* cost, double* ret, int32_t* finite, void* stream) {
+    if (!env || !x0 || !K || !kff || !xref || !uref || !weighting || !alphas_host) return TRAJOPT_ERR_BAD_ARG;
+    if (nb_steps <= 0 || nb_problems <= 0 || nb_alphas <= 0 || nb_alphas > TRAJOPT_MAX_ALPHAS) return TRAJOPT_ERR_BAD_ARG;
+    if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
+    return launch_rollout(env, nb_steps, nb_problems, layout, x0, K, kff, xref, uref, weighting, alphas_host, nb_alphas,
+                          active, state, action, cost, ret, finite, as_stream(stream));
+}
+
+int trajopt_env_step_batched(const trajopt_env_t* env, const double* x, const double* u, const double* u_last,
+                             const double* a, int64_t nb_problems, int layout, double* xn, double* cost, void* stream) {
+    if (!env || !x || !u || nb_problems <= 0) return TRAJOPT_ERR_BAD_ARG;
+    if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
+    StepLaunch L;
+    L.a.env = *env; L.a.x = x; L.a.u = u; L.a.u_last = u_last; L.a.a = a; L.a.xn = xn; L.a.cost = cost;
+    L.a.NP = (size_t)nb_problems; L.layout = layout; L.st = as_stream(stream);
+    if (!dispatch_model(*env, L)) return TRAJOPT_ERR_UNSUPPORTED;
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+// Register-resident tiny dense algebra for the thread-per-problem kernels.  Every loop bound is a
+// template constant so hipcc unrolls fully and the arrays live in VGPRs (no runtime indexing).
+#pragma once
+#include "common.h"
+
+namespace trajopt {
+
+// Positive-definiteness test of the M x M matrix X (column-major) with the tolerance rule Armadillo's
+// is_sympd() applies at /root/reference/trajopt/ilqr/src/util.cpp:145:
+//   tol = 100 eps ||X||_F;  ||X - X^T||_inf / ||X||_inf <= tol;  chol(X - tol I) succeeds.
+// On success L (lower, column-major) holds the Cholesky factor of X itself (not of X - tol I), which
+// then solves for the gains (util.cpp:150-152 uses inv()).
+template <int M>
+__device__ __forceinline__ bool sympd_factor(const double (&X)[M * M], double (&L)[M * M]) {
+    if constexpr (M == 1) {
+        const double q = X[0];
+        const double tol = 100.0 * kEps * fabs(q);
+        if (!(q - tol > 0.0)) return false;
+        L[0] = sqrt(q);
+        return true;
+    } else {
+        double fro = 0.0;
+#pragma unroll
+        for (int k = 0; k < M * M; ++k) fro = fma(X[k], X[k], fro);
+        fro = sqrt(fro);
+        const double tol = 100.0 * kEps * fro;
+        double na = 0.0, nd = 0.0;
+        bool nan_seen = false;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double ra = 0.0, rd = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                ra += fabs(X[i + M * j]);
+                rd += fabs(X[i + M * j] - X[j + M * i]);
+            }
+            nan_seen = nan_seen || (ra != ra);
+            na = fmax(na, ra);
+            nd = fmax(nd, rd);
+        }
+        if (nan_seen) return false;
+        if (na != 0.0 && !((nd / na) <= tol)) return false;
+        // pivots of X - tol I must all be positive
+        {
+            double Y[M * M];
+#pragma unroll
+            for (int k = 0; k < M * M; ++k) Y[k] = X[k];
+#pragma unroll
+            for (int i = 0; i < M; ++i) Y[i + M * i] -= tol;
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                double d = Y[j + M * j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) d = fma(-Y[j + M * k], Y[j + M * k], d);
+                ok = ok && (d > 0.0);
+                d = sqrt(d);
+                Y[j + M * j] = d;
+                const double inv = 1.0 / d;
+#pragma unroll
+                for (int i = j + 1; i < M; ++i) {
+                    double s = Y[i + M * j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) s = fma(-Y[i + M * k], Y[j + M * k], s);
+                    Y[i + M * j] = s * inv;
+                }
+            }
+            if (!ok) return false;
+        }
+#pragma unroll
+        for (int k = 0; k < M * M; ++k) L[k] = X[k];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            double d = L[j + M * j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) d = fma(-L[j + M * k], L[j + M * k], d);
+            d = sqrt(d);
+            L[j + M * j] = d;
+#pragma unroll
+            for (int i = j + 1; i < M; ++i) {
+                double s = L[i + M * j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) s = fma(-L[i + M * k], L[j + M * k], s);
+                L[i + M * j] = s / d;
+            }
+        }
+        return true;
+    }
+}
+
+// x := (L L^T)^{-1} x for one right-hand side of length M.
+template <int M>
+__device__ __forceinline__ void chol_solve(const double (&L)[M * M], double (&x)[M]) {
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        double s = x[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s = fma(-L[i + M * k], x[k], s);
+        x[i] = s / L[i + M * i];
+    }
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+        double s = x[i];
+#pragma unroll
+        for (int k = i + 1; k < M; ++k) s = fma(-L[k + M * i], x[k], s);
+        x[i] = s / L[i + M * i];
+    }
+}
+
+// np.max / Armadillo-free NaN-propagating max used for the gradient norm (ilqr.py:176).
+__device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? (a + b) : fmax(a, b); }
+
+}  // namespace trajopt

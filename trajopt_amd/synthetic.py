@@ -1,0 +1,47 @@
+"""Synthetic inputs for the backward pass in isolation.
+
+Per problem p and step t:  A = I + dt*G/sqrt(n), G ~ N(0,1), dt = 0.01;  B = dt*N(0,1);
+Cxx = M^T M / n + 1e-3 I;  Cuu = S^T S / m + 1e-2 I;  Cxu = 1e-2 N(0,1);  cx, cu ~ N(0,1);
+c ~ 1e-2 N(0,1) (Riccati form only).  Seed: numpy Generator(PCG64(1337)), the seed the reference
+examples use (/root/reference/examples/riccati/lqr.py:6).
+
+Returned arrays are "problem-major": shape (N, rows, cols, T) / (N, rows, T) whose per-problem slices
+are Fortran-ordered exactly like the reference's arguments (util.cpp:10,21); `to_layout` converts.
+"""
+import numpy as np
+
+SEED = 1337
+
+
+def backward_inputs(n, m, T, N, seed=SEED, affine=False, dt=0.01):
+    rng = np.random.Generator(np.random.PCG64(seed))
+
+    def fo(shape):  # (N, T, cols, rows) C-order  ==  per-problem F-order (rows, cols, T)
+        return rng.standard_normal(shape)
+
+    G = fo((N, T, n, n))
+    A = np.eye(n)[None, None] + dt * G / np.sqrt(n)
+    B = dt * fo((N, T, m, n))
+    M = fo((N, T + 1, n, n))
+    Cxx = np.einsum("ptki,ptkj->ptij", M, M) / n + 1e-3 * np.eye(n)[None, None]
+    S = fo((N, T + 1, m, m))
+    Cuu = np.einsum("ptki,ptkj->ptij", S, S) / m + 1e-2 * np.eye(m)[None, None]
+    Cxu = 1e-2 * fo((N, T + 1, m, n))
+    cx = fo((N, T + 1, n))
+    cu = fo((N, T + 1, m))
+    out = dict(A=A, B=B, Cxx=Cxx, Cuu=Cuu, Cxu=Cxu, cx=cx, cu=cu)
+    if affine:
+        out["c"] = 1e-2 * fo((N, T, n))
+    # stored as (N, T, cols, rows): present them as (N, rows, cols, T) views with the same memory
+    res = {}
+    for k, a in out.items():
+        if a.ndim == 4:
+            res[k] = np.ascontiguousarray(a).transpose(0, 3, 2, 1)
+        else:
+            res[k] = np.ascontiguousarray(a).transpose(0, 2, 1)
+    return res
+
+
+def problem(stack, p):
+    """Reference-layout (Fortran-ordered) arrays of problem p."""
+    return {k: np.asfortranarray(a[p]) for k, a in stack.items()}
