@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py - problem-timesteps/sec of one batched iLQR iteration on MI355X (BASELINE.json metric).
+
+A "step" is ONE full batched iLQR iteration over the whole batch, exactly the body of the reference's
+`for iter in range(nb_iter)` (/root/reference/trajopt/ilqr/ilqr.py:151-231): quadratise the dynamics and the
+cost along the current trajectory -> regularised Riccati backward pass (lambda retries inside the kernel)
+-> forward rollout + cost for all 11 alphas -> first-accept line search, accept/reject, lambda update.
+Workload = BASELINE config C2: cartpole (dx=4, du=1), T=500, 4096 instances per GPU, fp64, synthetic
+initial states x0 + N(0, sigma0) (seed 1337), resident in HBM before the timed region.  The stopping rules
+(tolfun / tolgrad / max_lmbda) are disabled so that every problem does a full iteration in every timed step.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Multi-GPU: problems are independent, so each rank owns its own 4096 instances (weak scaling) and there is
+no data-path collective; RCCL is used for the barrier and to take the max time over ranks.
+Rank 0 prints one JSON line (see DESIGN.md "Measurement" for the roofline / cpu_baseline definitions).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+PHASES = ("prep", "quadratize", "backward", "post_backward", "rollout", "select_commit")
+
+
+def alg_bytes_per_problem_step(n, m, nb_alphas):
+    """ALGORITHMIC HBM bytes per problem-timestep of each kernel (fp64; every array touched once).
+    backward: SURVEY 8(d) gains-only form.  quadratize: reads xref, uref; writes A, B, Cxx, cx, Cuu, cu, Cxu.
+    rollout: reads K, kff, xref, uref once; writes the state/action of ONE (the accepted) candidate - the other
+    candidates' stores are a design cost of the parallel line search, not algorithmic bytes."""
+    return {
+        "backward": 8 * (2 * n * n + 3 * n * m + m * m + n + 2 * m),
+        "quadratize": 8 * (2 * n * n + 2 * n * m + m * m + 2 * n + 2 * m),
+        "rollout": 8 * (n * m + 2 * m + n) + 8 * (n + m),
+        "select_commit": 2 * 8 * (n + m + n * m + m),
+    }
+
+
+def make_problem_set(env, N, T, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x0 = np.asarray(env.x0)[None] + rng.multivariate_normal(np.zeros(env.dm_state), env.sigma0, size=N)
+    kff0 = 1e-4 * rng.standard_normal((N, env.dm_act, T))
+    return x0, kff0
+
+
+def cpu_baseline(env_name, dt, uw, T, seed, budget_s=12.0):
+    """The CPU oracle's iLQR (the dependency-free C++ restatement of util.cpp + ilqr.py; kind "port": the
+    reference's Armadillo/autograd path cannot be built here) on a bounded sample of the same workload, one
+    problem per thread on the host cores."""
+    from oracle import oracle as O
+    from trajopt_amd import envs
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    cores = max(1, min(cores, os.cpu_count() or 1))
+    oe = O.make_env(env_name, dt=dt, uw=[uw])
+    pe = envs.make(env_name, dt=dt, uw=uw)
+    iters = 4
+    opts = [1., 1., 1e-6, float("inf"), 1.6, -float("inf"), 0.0, 0.]   # stopping disabled, as the GPU run
+    done_steps, elapsed, problems, chunk = 0, 0.0, 0, 4 * cores
+    while elapsed < budget_s and problems < 65536:
+        x0, kff0 = make_problem_set(pe, chunk, T, seed + 7919 + problems)
+        sec, _, it = O.bench_ilqr(oe, T, x0, kff0.reshape(chunk, -1), iters, cores, opts=opts)
+        elapsed += sec
+        done_steps += it * T
+        problems += chunk
+    return {"value": done_steps / elapsed, "unit": "problem-timesteps/s", "cores": cores, "kind": "port",
+            "sample": "%d cartpole problems x T=%d x %d iLQR iterations (sequential first-accept line search), "
+                      "%.1f s on %d threads, oracle/liboracle.so -O3" % (problems, T, iters, elapsed, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--instances", type=int, default=4096, help="problems per GPU (C2: 4096)")
+    ap.add_argument("--horizon", type=int, default=500)
+    ap.add_argument("--env", default="cartpole")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus > 1 launch with python -m torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from trajopt_amd import _lib, envs
+    from trajopt_amd.ilqr import BatchedILQR
+
+    dt, uw = {"cartpole": (0.02, 1e-5), "pendulum": (0.05, 1e-5), "double_cartpole": (0.01, 1e-5),
+              "quadrotor": (0.02, 1e-3)}[a.env]
+    env = envs.make(a.env, dt=dt, uw=uw)
+    N, T, K, W = a.instances, a.horizon, a.steps, a.warmup
+    n, m = env.dm_state, env.dm_act
+    x0, kff0 = make_problem_set(env, N, T, 1337 + rank)
+    solver = BatchedILQR(env, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False,
+                         tolfun=-float("inf"), tolgrad=0.0, max_lmbda=float("inf"))
+    nb_alphas = solver.alphas.size
+    solver.init_rollout()
+    solver.iterate(W)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    L = _lib.lib()
+    fence()
+    _lib.check(L.trajopt_profile_begin(K))
+    t0 = time.perf_counter()
+    solver.iterate(K)
+    fence()
+    t1 = time.perf_counter()
+    phase_ms = (C.c_double * len(PHASES))()
+    nrec = C.c_int(0)
+    _lib.check(L.trajopt_profile_end(phase_ms, C.byref(nrec)))
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    status = solver.host("status")
+    iters = solver.host("iters")
+    assert np.all(status == 0) and np.all(iters == W + K), "a problem stopped inside the timed region"
+    ret = solver.host("last_return")
+    assert np.all(np.isfinite(ret)), "non-finite trajectory cost"
+
+    if rank == 0:
+        phases = {k: phase_ms[i] / max(nrec.value, 1) for i, k in enumerate(PHASES)}
+        dom = max(("quadratize", "backward", "rollout", "select_commit"), key=lambda k: phases[k])
+        ab = alg_bytes_per_problem_step(n, m, nb_alphas)
+        per_launch = ab[dom] * N * T
+        achieved = per_launch / (phases[dom] * 1e-3) / 1e9
+        bwd_gbs = ab["backward"] * N * T / (phases["backward"] * 1e-3) / 1e9
+        out = {
+            "metric": "problem-timesteps/sec (iLQR iteration, batched)",
+            "value": world * N * T * K / elapsed,
+            "unit": "problem-timesteps/s",
+            "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: batched iLQR %s dx=%d du=%d T=%d, %d instances per GPU, %d alphas, reg=1, "
+                                   "stopping rules disabled" % (a.env, n, m, T, N, nb_alphas),
+                       "instances_per_gpu": N, "horizon": T, "parallelism": "problems sharded x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": per_launch, "avg_launch_ms": phases[dom]},
+            "phase_ms": phases,
+            "backward_pass_GBps": bwd_gbs,
+            "mean_return": float(ret.mean()),
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.env, dt, uw, T, 1337, a.cpu_budget)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

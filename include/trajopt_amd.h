@@ -223,6 +223,15 @@ int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_optio
 int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
                          const trajopt_ilqr_workspace_t* ws, int nb_iter, void* stream);
 
+/* Per-phase device timing of trajopt_ilqr_iterate (measurement aid; no counterpart in the reference, which
+ * has no timers).  begin() creates hipEvents for up to `max_iterations` iterations; while enabled, iterate
+ * records them on ITS launch stream around the six phases  prep | quadratise | backward | post-backward |
+ * rollout | select+commit.  end() waits for the last event, writes the summed milliseconds per phase to
+ * phase_ms[6] and the number of recorded iterations, and disables recording.  Not thread-safe. */
+#define TRAJOPT_PROFILE_PHASES 6
+int trajopt_profile_begin(int max_iterations);
+int trajopt_profile_end(double* phase_ms, int* nb_iterations);
+
 /* Layout conversion helper (device to device): dst = src re-laid-out; rows*cols*slices elements/problem. */
 int trajopt_convert_layout(const double* src, double* dst, int64_t elems_per_problem, int64_t nb_problems,
                            int src_layout, int dst_layout, void* stream);

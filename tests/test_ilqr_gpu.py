@@ -1,0 +1,297 @@
+"""GPU parity of env models, rollout, quadratisation and the batched iLQR driver (rows A3-A8, A10)
+against the CPU oracle, through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import TOL, assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+ENVS = ["pendulum", "cartpole", "double_cartpole", "quadrotor", "lqr"]
+
+
+def _pair(name, **kw):
+    """(product env, oracle env struct) with identical parameters."""
+    from oracle import oracle as O
+    from trajopt_amd import envs
+    pe = envs.make(name, **kw)
+    okw = dict(kw)
+    if "uw" in okw:
+        okw["uw"] = list(np.asarray(okw["uw"], dtype=float) * np.ones(pe.dm_act))
+    oe = O.make_env(name, **okw)
+    return pe, oe
+
+
+def _rand_state(name, rng, N):
+    n = {"pendulum": 2, "cartpole": 4, "double_cartpole": 6, "quadrotor": 12, "lqr": 2}[name]
+    x = rng.standard_normal((N, n))
+    if name == "quadrotor":
+        x[:, 3:6] *= 0.3  # keep away from the Euler singularity
+    return x
+
+
+def test_env_struct_matches_oracle_struct():
+    for name in ENVS:
+        for kw in ({}, dict(dt=0.05, uw=[1e-2] if name != "quadrotor" else [1e-2] * 4, slew_rate=True, periodic=True)):
+            pe, oe = _pair(name, **kw)
+            assert bytes(pe.struct()) == bytes(oe), name
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("name", ENVS)
+def test_env_step_matches_oracle(oracle, name, layout):
+    import torch
+    from trajopt_amd import _lib, layout as L
+    pe, oe = _pair(name, slew_rate=True, periodic=(name != "lqr" and name != "quadrotor"))
+    rng = np.random.default_rng(3)
+    N = 130
+    n, m = pe.dm_state, pe.dm_act
+    x = 3.0 * _rand_state(name, rng, N)
+    u = 8.0 * rng.standard_normal((N, m))          # some beyond umax: exercises the clip
+    ul = rng.standard_normal((N, m))
+    a = rng.uniform(0.1, 2.0, N)
+    a[::7] = 0.0                                   # `if a:` drops the state cost
+    e = pe.struct()
+    dx, du, dul = (torch.as_tensor(np.ascontiguousarray(v if layout == 0 else v.T), device="cuda")
+                   for v in (x, u, ul))
+    da = torch.as_tensor(a, device="cuda")
+    xn = torch.empty_like(dx)
+    cost = torch.empty(N, dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib().trajopt_env_step_batched(C.byref(e), _lib.dptr(dx), _lib.dptr(du), _lib.dptr(dul),
+                                                   _lib.dptr(da), C.c_int64(N), layout, _lib.dptr(xn), _lib.dptr(cost),
+                                                   _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    xn = xn.cpu().numpy() if layout == 0 else xn.cpu().numpy().T
+    cost = cost.cpu().numpy()
+    for p in range(N):
+        assert_close(xn[p], oracle.env_dynamics(oe, x[p], u[p]), "%s xn[%d]" % (name, p), tol=1e-12)
+        c = oracle.env_cost(oe, x[p], u[p], ul[p], a[p])
+        assert abs(cost[p] - c) <= 1e-12 * max(abs(c), 1e-300), (name, p, cost[p], c)
+
+
+def _rollout_inputs(name, rng, N, T, n, m):
+    xref = _rand_state(name, rng, N)[:, :, None] + 0.1 * rng.standard_normal((N, n, T + 1))
+    uref = rng.standard_normal((N, m, T))
+    # the quadrotor's attitude loop (inertia 4e-3) amplifies round-off e^(O(100 t)) under random gains:
+    # keep its rollouts tame so that 1e-9 tests the arithmetic, not the Lyapunov exponent
+    gs = 0.01 if name == "quadrotor" else 0.3
+    K = gs * rng.standard_normal((N, m, n, T))
+    kff = (0.1 if name == "quadrotor" else 1.0) * rng.standard_normal((N, m, T))
+    if name == "quadrotor":
+        uref = 1.2 + 0.05 * uref
+    x0 = xref[:, :, 0] + 0.05 * rng.standard_normal((N, n))
+    return x0, K, kff, xref, uref
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("name", ENVS)
+def test_forward_pass_matches_oracle(oracle, name, layout):
+    """ilqr.py:89-102 for several alphas at once; trajectory cost within 1e-9 (north_star)."""
+    import torch
+    from trajopt_amd import _lib, layout as L
+    pe, oe = _pair(name, dt=0.02 if name != "lqr" else None)
+    rng = np.random.default_rng(11)
+    N, T = 70, 40
+    n, m = pe.dm_state, pe.dm_act
+    x0, K, kff, xref, uref = _rollout_inputs(name, rng, N, T, n, m)
+    w = rng.uniform(0.5, 1.5, T + 1)
+    alphas = np.array([1.0, 0.5, 0.1])
+    e = pe.struct()
+    d = {k: L.to_device(v, layout) for k, v in dict(K=K, kff=kff, xref=xref, uref=uref).items()}
+    dx0 = torch.as_tensor(np.ascontiguousarray(x0 if layout == 0 else x0.T), device="cuda")
+    dw = torch.as_tensor(w, device="cuda")
+    na = len(alphas)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    state = torch.empty((na,) + L.device_shape((N, n, T + 1), layout), **f64)
+    action = torch.empty((na,) + L.device_shape((N, m, T), layout), **f64)
+    cost = torch.empty((na,) + L.device_shape((N, T + 1), layout), **f64)
+    ret = torch.empty((na, N), **f64)
+    fin = torch.empty((na, N), dtype=torch.int32, device="cuda")
+    arr = (C.c_double * na)(*alphas)
+    _lib.check(_lib.lib().trajopt_ilqr_forward_pass_batched(
+        C.byref(e), T, C.c_int64(N), layout, _lib.dptr(dx0), _lib.dptr(d["K"]), _lib.dptr(d["kff"]),
+        _lib.dptr(d["xref"]), _lib.dptr(d["uref"]), _lib.dptr(dw), arr, na, None, _lib.dptr(state), _lib.dptr(action),
+        _lib.dptr(cost), _lib.dptr(ret), _lib.dptr(fin), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    for ai, alpha in enumerate(alphas):
+        st, ac, co = (L.from_device(t[ai], layout) for t in (state, action, cost))
+        for p in range(0, N, 3):
+            rs, ra, rc = oracle.forward_pass(oe, T, x0[p], K[p], kff[p], alpha, xref[p], uref[p], w)
+            assert_close(st[p], rs, "state")
+            assert_close(ac[p], ra, "action")
+            assert_close(co[p], rc, "cost")
+            assert abs(ret[ai, p].item() - rc.sum()) <= TOL * abs(rc.sum())
+            assert fin[ai, p].item() == int(np.all(rs < 1e8))
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("convention", [0, 1])
+@pytest.mark.parametrize("name", ENVS)
+def test_quadratize_matches_oracle(oracle, name, layout, convention):
+    """objects.py:68-78,114-117 (and riccati/objects.py:54-65,102-108), incl. saturated inputs (clip mask),
+    slew-rate cost, periodic wrap and zero weights."""
+    import torch
+    from trajopt_amd import _lib, layout as L
+    periodic = name in ("pendulum", "cartpole", "double_cartpole")
+    pe, oe = _pair(name, slew_rate=True, periodic=periodic)
+    rng = np.random.default_rng(5)
+    N, T = 66, 12
+    n, m = pe.dm_state, pe.dm_act
+    xref = 2.0 * _rand_state(name, rng, N)[:, :, None] + 0.3 * rng.standard_normal((N, n, T + 1))
+    uref = 6.0 * rng.standard_normal((N, m, T))    # some saturated -> B columns vanish
+    uref[:, :, 3] = np.asarray(pe.umax) if name != "lqr" else 1.0   # exactly on the bound
+    w = rng.uniform(0.5, 1.5, T + 1)
+    w[2] = 0.0
+    e = pe.struct()
+    dx, du = L.to_device(xref, layout), L.to_device(uref, layout)
+    dw = torch.as_tensor(w, device="cuda")
+    shp = dict(A=(N, n, n, T), B=(N, n, m, T), c=(N, n, T), Cxx=(N, n, n, T + 1), cx=(N, n, T + 1),
+               Cuu=(N, m, m, T + 1), cu=(N, m, T + 1), Cxu=(N, n, m, T + 1))
+    o = {k: L.empty(s, layout, zero=True) for k, s in shp.items()}
+    _lib.check(_lib.lib().trajopt_quadratize_batched(
+        C.byref(e), T, C.c_int64(N), layout, convention, _lib.dptr(dx), _lib.dptr(du), _lib.dptr(dw), None,
+        _lib.dptr(o["A"]), _lib.dptr(o["B"]), _lib.dptr(o["c"]), _lib.dptr(o["Cxx"]), _lib.dptr(o["cx"]),
+        _lib.dptr(o["Cuu"]), _lib.dptr(o["cu"]), _lib.dptr(o["Cxu"]), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    h = {k: L.from_device(v, layout) for k, v in o.items()}
+    keys = list(shp) if convention == 1 else [k for k in shp if k != "c"]
+    for p in range(0, N, 5):
+        ref = oracle.quadratize(oe, T, xref[p], uref[p], w, riccati=bool(convention))
+        for k in keys:
+            den = max(np.abs(ref[k]).max(), 1.0)
+            assert np.abs(h[k][p] - ref[k]).max() <= 1e-10 * den, "%s %s[%d]" % (name, k, p)
+
+
+def _solve_pair(oracle, name, N, T, iters, seed=1337, scale=1e-2, **kw):
+    from trajopt_amd.ilqr import BatchedILQR
+    pe, oe = _pair(name, **kw)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x0 = np.asarray(pe.x0)[None] + scale * rng.standard_normal((N, pe.dm_state))
+    kff0 = 1e-4 * rng.standard_normal((N, pe.dm_act, T))
+    s = BatchedILQR(pe, T, x0, kff_init=kff0, action_penalty=None, keep_value=True, apply_env_kwargs=False)
+    traces = s.run(nb_iter=iters)
+    refs = [oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=iters) for p in range(N)]
+    return s, traces, refs
+
+
+@pytest.mark.parametrize("name,T,iters,kw", [
+    ("pendulum", 100, 5, dict(dt=0.05, uw=[1e-5])),           # config C1's shape (examples/ilqr/mpc/pendulum.py)
+    ("cartpole", 60, 4, dict(dt=0.02, uw=[1e-5])),
+    ("double_cartpole", 50, 3, dict(dt=0.01, uw=[1e-5])),
+    ("quadrotor", 40, 3, dict(dt=0.02)),
+    ("lqr", 60, 5, dict()),
+])
+def test_batched_driver_matches_oracle_driver(oracle, name, T, iters, kw):
+    """ilqr.py:136-237 per problem: same accepted iterates, lambda schedule, traces and stop reasons."""
+    N = 37
+    s, traces, refs = _solve_pair(oracle, name, N, T, iters, **kw)
+    lam, dlam, st, it = s.host("lmbda"), s.host("dlmbda"), s.host("status"), s.host("iters")
+    xref, uref, K, kff, V, v = (s.host(k) for k in ("xref", "uref", "K", "kff", "V", "v"))
+    ret = s.host("last_return")
+    for p in range(N):
+        r = refs[p]
+        assert len(traces[p]) == len(r["trace"]), (p, traces[p], r["trace"])
+        assert_close(np.array(traces[p]), r["trace"], "trace[%d]" % p)
+        assert abs(ret[p] - r["last_return"]) <= TOL * abs(r["last_return"])
+        assert lam[p] == pytest.approx(r["lmbda"], rel=1e-14) and dlam[p] == pytest.approx(r["dlmbda"], rel=1e-14)
+        assert st[p] == r["status"] and it[p] == r["iters"]
+        assert_close(xref[p], r["xref"], "xref", tol=1e-8)
+        assert_close(uref[p], r["uref"], "uref", tol=1e-8)
+        if len(r["trace"]) > 1:
+            assert_close(K[p], r["K"], "K", tol=1e-8)
+            assert_close(kff[p], r["kff"], "kff", tol=1e-7)
+            assert_close(V[p], r["V"], "V", tol=1e-8)
+            assert_close(v[p], r["v"], "v", tol=1e-8)
+
+
+def test_lq_problem_converges_in_one_step_with_exact_expected_reduction(oracle):
+    """Known answer (SURVEY 8c iii): on an LQ problem with lmbda -> 0 and alpha = 1 the actual cost drop equals
+    -(dV[0] + dV[1]) and the next iteration stops on the gradient-norm rule."""
+    from trajopt_amd import envs
+    from trajopt_amd.ilqr import BatchedILQR
+    env = envs.make("lqr")
+    N, T = 8, 30
+    rng = np.random.default_rng(0)
+    x0 = np.asarray(env.x0)[None] + rng.standard_normal((N, 2))
+    s = BatchedILQR(env, T, x0, kff_init=np.zeros((N, 1, T)), action_penalty=None, apply_env_kwargs=False,
+                    lmbda=0.0, min_lmbda=0.0)
+    s.init_rollout()
+    r0 = s.host("last_return").copy()
+    s.iterate(1)
+    r1 = s.host("last_return")
+    dV = s._dV.cpu().numpy()
+    assert np.all(s.host("alpha") == 1.0)
+    np.testing.assert_allclose(r0 - r1, -(dV[0] + dV[1]), rtol=1e-8)
+    s.iterate(1)   # converged: the gradient-norm rule fires before any rollout (ilqr.py:176-180)
+    assert np.all(s.host("status") == 1)
+
+
+def test_argmin_alpha_option_never_worse_than_first_accept(oracle):
+    from trajopt_amd import envs
+    from trajopt_amd.ilqr import BatchedILQR
+    rng = np.random.default_rng(4)
+    N, T = 64, 50
+    x0 = np.array([0., np.pi, 0., 0.])[None] + 1e-2 * rng.standard_normal((N, 4))
+    kff0 = 1e-4 * rng.standard_normal((N, 1, T))
+    out = []
+    for argmin in (False, True):
+        env = envs.make("cartpole", dt=0.02)
+        s = BatchedILQR(env, T, x0, kff_init=kff0, action_penalty=1e-5, argmin_alpha=argmin)
+        s.run(nb_iter=1)
+        out.append(s.host("last_return").copy())
+    assert np.all(out[1] <= out[0] * (1 + 1e-12))
+
+
+def test_ilqr_class_is_a_drop_in_for_the_reference_usage(oracle):
+    """The call pattern of /root/reference/examples/ilqr/mpc/pendulum.py:18-31 (one MPC step)."""
+    from trajopt_amd import envs
+    from trajopt_amd.ilqr import iLQR
+    env = envs.make('Pendulum-TO-v0')
+    env.unwrapped.dt = 0.05
+    np.random.seed(1337)
+    state = np.array([np.pi, 0.])
+    solver = iLQR(env, init_state=state, nb_steps=20, action_penalty=np.array([1e-5]))
+    kff0 = solver.ctl.kff.copy()
+    trace = solver.run(nb_iter=10, verbose=False)
+    oe = oracle.make_env("pendulum", dt=0.05, uw=[1e-5])
+    ref = oracle.ilqr_run(oe, 20, state, kff0, nb_iter=10)
+    assert_close(np.array(trace), ref["trace"], "trace")
+    assert solver.uref.shape == (1, 20) and solver.xref.shape == (2, 21)
+    assert_close(solver.uref, ref["uref"], "uref", tol=1e-8)
+    assert_close(solver.ctl.K, ref["K"], "K", tol=1e-8)
+    assert_close(solver.vfunc.V, ref["V"], "V", tol=1e-8)
+    assert solver.lmbda == pytest.approx(ref["lmbda"], rel=1e-14)
+    # the individual methods keep the reference's signatures and shapes
+    st, ac, co = solver.forward_pass(solver.ctl, 0.5)
+    rs, ra, rc = oracle.forward_pass(oe, 20, state, solver.ctl.K, solver.ctl.kff, 0.5, solver.xref, solver.uref,
+                                     np.ones(21))
+    assert st.shape == (2, 21) and ac.shape == (1, 20) and co.shape == (21,)
+    assert_close(st, rs, "state"); assert_close(co, rc, "cost")
+    solver.dyn.taylor_expansion(solver.xref, solver.uref)
+    solver.cost.taylor_expansion(solver.xref, solver.uref, solver.weighting)
+    lc, xvalue, xuvalue, dV, diverge = solver.backward_pass()
+    q = oracle.quadratize(oe, 20, solver.xref, solver.uref, np.ones(21))
+    rb, _ = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], solver.lmbda, 1, 2, 1, 20)
+    assert_close(lc.K, rb[8], "K"); assert_close(xvalue.V, rb[5], "V"); assert_close(xuvalue.Qux, rb[1], "Qux")
+    assert_close(dV, rb[7], "dV"); assert diverge == 0
+
+
+def test_riccati_class_on_the_lqr_env_reaches_the_dare_gain(oracle):
+    """examples/riccati/lqr.py:9-18 call pattern; known answer: K_0 -> -(R + B'PB)^-1 B'PA (SURVEY 8c i)."""
+    import scipy.linalg
+    from trajopt_amd import envs
+    from trajopt_amd.riccati import Riccati
+    env = envs.make('LQR-TO-v0')
+    env.seed(1337)
+    T = 150
+    solver = Riccati(env, nb_steps=T, init_state=env.init())
+    ret = solver.run()
+    assert np.isfinite(ret)
+    A, B = env.A, env.B
+    Q, R = env.dt * np.diag(env.gw), env.dt * np.diag(env.uw)
+    P = scipy.linalg.solve_discrete_are(A, B, Q, R)
+    Kinf = -np.linalg.solve(R + B.T @ P @ B, B.T @ P @ A)
+    np.testing.assert_allclose(solver.ctl.K[..., 0], Kinf, rtol=1e-9)
+    np.testing.assert_allclose(solver.vfunc.V[..., 0], P, rtol=1e-8)  # scipy DARE accuracy

@@ -43,7 +43,8 @@ __global__ void init_select_kernel(DrvArgs a) {
     for (int k = 0; k < a.opt.nb_alphas; ++k)
         if (a.ws.cand_finite[(size_t)k * NP + p]) { sel = k; break; }
     a.ws.sel[p] = sel;
-    const double r = sel >= 0 ? a.ws.cand_ret[(size_t)sel * NP + p] : -INFINITY;  // ilqr.py:87
+    // no finite alpha: last_return keeps its previous value (-inf on a fresh solver, ilqr.py:87)
+    const double r = sel >= 0 ? a.ws.cand_ret[(size_t)sel * NP + p] : a.ws.last_return[p];
     a.ws.last_return[p] = r;
     a.ws.trace[p] = r;  // ilqr.py:149
     a.ws.trace_len[p] = 1;
@@ -158,6 +159,20 @@ __global__ void commit_kernel(DrvArgs a, int with_ctl) {
     }
 }
 
+// ---- optional per-phase timing of trajopt_ilqr_iterate (bench.py's roofline leg) ------------------------
+// hipEvents recorded on the launch stream around each phase of an iteration.  Events are created by
+// trajopt_profile_begin(), never inside iterate; with profiling off iterate records nothing.
+constexpr int kPhases = 6;  // prep | quadratise | backward | post-backward | rollout | select+commit
+struct Profile {
+    bool on = false;
+    int cap = 0, used = 0;
+    hipEvent_t* ev = nullptr;  // (kPhases + 1) events per recorded iteration
+};
+static Profile g_prof;
+static inline void prof_mark(hipStream_t st, int slot, int k) {
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev[(size_t)slot * (kPhases + 1) + k], st);
+}
+
 static int check_ws(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt, const trajopt_ilqr_workspace_t* ws) {
     if (!env || !opt || !ws) return TRAJOPT_ERR_BAD_ARG;
     if (ws->nb_steps <= 0 || ws->nb_problems <= 0 || opt->nb_alphas <= 0 || opt->nb_alphas > TRAJOPT_MAX_ALPHAS)
@@ -226,22 +241,62 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
     io.dV = ws->dV; io.K = ws->cand_K; io.kff = ws->cand_kff; io.diverge = ws->diverge;
     io.uref = ws->uref; io.g_norm = ws->g_norm; io.active = ws->active;
     for (int it = 0; it < nb_iter; ++it) {
+        const int slot = (g_prof.on && g_prof.used < g_prof.cap) ? g_prof.used++ : -1;
+        prof_mark(st, slot, 0);
         hipLaunchKernelGGL(prep_kernel, dim3(g1), dim3(256), 0, st, a);
+        prof_mark(st, slot, 1);
         rc = launch_quadratize(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 0, ws->xref, ws->uref, ws->weighting,
                                ws->active, ws->A, ws->B, nullptr, ws->Cxx, ws->cx, ws->Cuu, ws->cu, ws->Cxu, st);
         if (rc != TRAJOPT_OK) return rc;
+        prof_mark(st, slot, 2);
         rc = trajopt_ilqr_backward_pass_batched(&io, opt->reg, n, m, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 1,
                                                 &opt->sched, st);
         if (rc != TRAJOPT_OK) return rc;
+        prof_mark(st, slot, 3);
         hipLaunchKernelGGL(post_backward_kernel, dim3(g1), dim3(256), 0, st, a);
+        prof_mark(st, slot, 4);
         rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
                             ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                             ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st);
         if (rc != TRAJOPT_OK) return rc;
+        prof_mark(st, slot, 5);
         hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a);
         hipLaunchKernelGGL(commit_kernel, dim3(g2), dim3(256), 0, st, a, 1);
+        prof_mark(st, slot, 6);
     }
     TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+int trajopt_profile_begin(int max_iterations) {
+    if (max_iterations <= 0) return TRAJOPT_ERR_BAD_ARG;
+    if (g_prof.ev) {
+        for (int i = 0; i < g_prof.cap * (kPhases + 1); ++i) (void)hipEventDestroy(g_prof.ev[i]);
+        delete[] g_prof.ev;
+        g_prof.ev = nullptr;
+    }
+    g_prof.ev = new hipEvent_t[(size_t)max_iterations * (kPhases + 1)];
+    for (int i = 0; i < max_iterations * (kPhases + 1); ++i) TRAJOPT_HIP_CHECK(hipEventCreate(&g_prof.ev[i]));
+    g_prof.cap = max_iterations;
+    g_prof.used = 0;
+    g_prof.on = true;
+    return TRAJOPT_OK;
+}
+
+int trajopt_profile_end(double* phase_ms, int* nb_iterations) {
+    if (!phase_ms || !nb_iterations || !g_prof.ev) return TRAJOPT_ERR_BAD_ARG;
+    g_prof.on = false;
+    for (int k = 0; k < kPhases; ++k) phase_ms[k] = 0.0;
+    for (int i = 0; i < g_prof.used; ++i) {
+        hipEvent_t* e = g_prof.ev + (size_t)i * (kPhases + 1);
+        TRAJOPT_HIP_CHECK(hipEventSynchronize(e[kPhases]));
+        for (int k = 0; k < kPhases; ++k) {
+            float ms = 0.f;
+            TRAJOPT_HIP_CHECK(hipEventElapsedTime(&ms, e[k], e[k + 1]));
+            phase_ms[k] += (double)ms;
+        }
+    }
+    *nb_iterations = g_prof.used;
     return TRAJOPT_OK;
 }
 

@@ -1,0 +1,267 @@
+"""Host-side mirror of the reference's env layer for the envs the hot path names (row A8).
+
+The reference's envs are gym.Env subclasses written in autograd.numpy
+(/root/reference/trajopt/envs/{pendulum/pendulum.py, cartpole/cartpole.py,
+double_cartpole/double_cartpole.py, lqr/lqr_v0.py}) and are consumed by iLQR only through
+`env.unwrapped.dynamics / .cost`, `env.action_space.high / .shape`, `env.observation_space.shape`
+and the writable `env.unwrapped.slew_rate / .uw` (/root/reference/trajopt/ilqr/ilqr.py:23-36).
+Here an env is a parameter bag with the same attribute names (dm_state, dm_act, dt, g, gw, uw, umax,
+xmax, x0, sigma0, sigma, slew_rate, periodic) whose `struct()` is the POD the HIP kernels take
+(include/trajopt_env.h); `dynamics` and `cost` evaluate ON THE DEVICE through
+trajopt_env_step_batched - there is no host implementation of the physics in this package.
+gym is not imported (absent in the build image); `make()` understands the reference's ids.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_PENDULUM, ENV_QUADROTOR, MAX_ACT, MAX_STATE,
+                   EnvStruct)
+
+
+class Box:
+    """The two attributes of gym.spaces.Box the solvers read."""
+
+    def __init__(self, low, high):
+        self.low = np.atleast_1d(np.asarray(low, dtype=np.float64))
+        self.high = np.atleast_1d(np.asarray(high, dtype=np.float64))
+        self.shape = self.high.shape
+
+
+class Env:
+    model = None
+    phys = ()
+    angles = ()          # indices wrapped by the cost when `periodic` (e.g. cartpole.py:121-122)
+    cost_times_dt = False
+
+    def __init__(self):
+        self.slew_rate = False
+        self.periodic = False
+        self.state = None
+        self.np_random = None
+        self.seed()
+
+    # -- gym surface ---------------------------------------------------------------------------
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def observation_space(self):
+        return Box(-np.asarray(self.xmax), np.asarray(self.xmax))
+
+    @property
+    def action_space(self):
+        u = np.broadcast_to(np.asarray(self.umax, dtype=np.float64), (self.dm_act,))
+        return Box(-u, u)
+
+    @property
+    def xlim(self):
+        return self.xmax
+
+    @property
+    def ulim(self):
+        return self.umax
+
+    def seed(self, seed=None):
+        self.np_random = np.random.RandomState(seed)  # gym.utils.seeding.np_random of the reference's era
+        return [seed]
+
+    def init(self):
+        return self.x0, self.sigma0
+
+    def reset(self):
+        self.state = self.np_random.multivariate_normal(mean=self.x0, cov=self.sigma0)
+        return self.state
+
+    def noise(self, x=None, u=None):
+        return self.sigma
+
+    def step(self, u):
+        _sigma = self.noise(self.state, u)
+        self.state = self.dynamics(self.state, u)
+        self.state = self.np_random.multivariate_normal(mean=self.state, cov=_sigma)
+        return self.state, [], False, {}
+
+    # -- device struct -------------------------------------------------------------------------
+    def struct(self):
+        """include/trajopt_env.h::trajopt_env_t from the CURRENT attribute values (the reference's
+        scripts mutate env.unwrapped.dt / .uw / .slew_rate after construction)."""
+        e = EnvStruct()
+        n, m = int(self.dm_state), int(self.dm_act)
+        if n > MAX_STATE or m > MAX_ACT:
+            raise _lib.TrajoptError("env dims (%d, %d) exceed (%d, %d)" % (n, m, MAX_STATE, MAX_ACT))
+        e.model, e.dm_state, e.dm_act = int(self.model), n, m
+        e.slew_rate = int(bool(self.slew_rate))
+        e.periodic = sum(1 << i for i in self.angles) if self.periodic else 0
+        e.cost_times_dt = int(bool(self.cost_times_dt))
+        e.dt = float(self.dt)
+
+        def fill(field, vals, cnt):
+            vals = np.broadcast_to(np.asarray(vals, dtype=np.float64), (cnt,))
+            for i in range(cnt):
+                field[i] = float(vals[i])
+
+        fill(e.umax, self.umax, m)
+        fill(e.xmax, self.xmax, n)
+        fill(e.goal, self.g, n)
+        fill(e.gw, self.gw, n)
+        fill(e.uw, self.uw, m)
+        for i, v in enumerate(self.phys):
+            e.phys[i] = float(v)
+        self._fill_linear(e)
+        return e
+
+    def _fill_linear(self, e):
+        pass
+
+    # -- single evaluations, on the device -----------------------------------------------------
+    def _step(self, x, u, u_last, a, want_cost):
+        import torch
+        _lib.require_gpu()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        n, m = self.dm_state, self.dm_act
+        xd = torch.as_tensor(np.asarray(x, dtype=np.float64).reshape(n), device=dev)
+        ud = torch.as_tensor(np.asarray(u, dtype=np.float64).reshape(m), device=dev)
+        uld = None if u_last is None else torch.as_tensor(np.asarray(u_last, dtype=np.float64).reshape(m), device=dev)
+        ad = None if a is None else torch.tensor([float(a)], dtype=torch.float64, device=dev)
+        out = torch.empty(1 if want_cost else n, dtype=torch.float64, device=dev)
+        e = self.struct()
+        _lib.check(_lib.lib().trajopt_env_step_batched(
+            C.byref(e), _lib.dptr(xd), _lib.dptr(ud), _lib.dptr(uld), _lib.dptr(ad), C.c_int64(1),
+            _lib.LAYOUT_PROBLEM_MINOR, None if want_cost else _lib.dptr(out), _lib.dptr(out) if want_cost else None,
+            _lib.stream_ptr()))
+        r = out.cpu().numpy()
+        return float(r[0]) if want_cost else r
+
+    def dynamics(self, x, u):
+        """xn = clip(RK4(x, clip(u)))  (e.g. cartpole.py:62-97)."""
+        return self._step(x, u, None, None, False)
+
+    def cost(self, x, u, u_last, a):
+        """u' diag(uw) u (or the slew form) + a (y - g)' diag(gw) (y - g)  (e.g. cartpole.py:112-127)."""
+        return self._step(x, u, u_last, a, True)
+
+
+class Pendulum(Env):
+    """/root/reference/trajopt/envs/pendulum/pendulum.py:15-149"""
+    model, angles = ENV_PENDULUM, (0,)
+    phys = (9.81, 1., 1., 1e-3)  # g, m, l, k  (pendulum.py:61)
+
+    def __init__(self):
+        self.dm_state, self.dm_act, self.dt = 2, 1, 0.01
+        self.sigma = 1e-4 * np.eye(2)
+        self.g, self.gw = np.array([0., 0.]), np.array([1e0, 1e-1])
+        self.xmax = np.array([np.inf, np.inf])
+        self.uw, self.umax = 1e-3 * np.ones(1), 10. * np.ones(1)
+        self.x0, self.sigma0 = np.array([np.pi, 0.]), 1e-4 * np.eye(2)
+        super().__init__()
+
+    def reset(self):  # pendulum.py:143-149
+        low, high = np.array([np.pi - np.pi / 10., -0.75]), np.array([np.pi + np.pi / 10., 0.75])
+        x0 = self.np_random.uniform(low=low, high=high)
+        self.state = np.hstack((((x0[0] + np.pi) % (2. * np.pi)) - np.pi, x0[1]))
+        return self.state
+
+
+class Cartpole(Env):
+    """/root/reference/trajopt/envs/cartpole/cartpole.py:15-147"""
+    model, angles = ENV_CARTPOLE, (1,)
+    phys = (9.81, 0.37, 0.127, 0.3365, 0.005)  # g, Mc, Mp, l, fr  (cartpole.py:67-72)
+
+    def __init__(self):
+        self.dm_state, self.dm_act, self.dt = 4, 1, 0.01
+        self.sigma = 1e-8 * np.eye(4)
+        self.g, self.gw = np.zeros(4), np.array([1e1, 1e4, 1e0, 1e0])
+        self.xmax = np.array([10., np.inf, np.inf, np.inf])
+        self.uw, self.umax = 1e-5 * np.ones(1), 10. * np.ones(1)
+        self.x0, self.sigma0 = np.array([0., np.pi, 0., 0.]), 1e-4 * np.eye(4)
+        super().__init__()
+
+
+class DoubleCartpole(Env):
+    """/root/reference/trajopt/envs/double_cartpole/double_cartpole.py:15-205"""
+    model, angles = ENV_DOUBLE_CARTPOLE, (1, 2)
+    phys = (9.81, 0.37, 0.127, 0.127, 0.3365, 0.3365)  # g, Mc, Mp1, Mp2, L1, L2  (double_cartpole.py:71-77)
+
+    def __init__(self):
+        self.dm_state, self.dm_act, self.dt = 6, 1, 0.01
+        self.sigma = 1e-8 * np.eye(6)
+        self.g, self.gw = np.zeros(6), np.array([1e1, 1e4, 1e4, 1e0, 1e0, 1e0])
+        self.xmax = np.array([10.] + [np.inf] * 5)
+        self.uw, self.umax = 1e-5 * np.ones(1), 5. * np.ones(1)
+        self.x0, self.sigma0 = np.array([0., np.pi, np.pi, 0., 0., 0.]), 1e-4 * np.eye(6)
+        super().__init__()
+
+
+class LQRv0(Env):
+    """/root/reference/trajopt/envs/lqr/lqr_v0.py:8-114: xn = A x + B clip(u) + c, cost scaled by dt.
+    A, B, c, g, gw, uw may be replaced (any dx <= 12, du <= 4) for the time-invariant LQ known-answer cases."""
+    model, cost_times_dt = ENV_LQR, True
+
+    def __init__(self, A=None, B=None, c=None, g=None, gw=None, uw=None, x0=None, dt=0.1):
+        self.A = np.array([[1.1, 0.], [1.0, 1.0]]) if A is None else np.asarray(A, dtype=np.float64)
+        self.B = np.array([[1.], [0.]]) if B is None else np.asarray(B, dtype=np.float64)
+        self.dm_state, self.dm_act = self.B.shape
+        self.dt = dt
+        self.g = np.full(self.dm_state, 10.) if g is None else np.asarray(g, dtype=np.float64)
+        self.c = -self.A @ self.g if c is None else np.asarray(c, dtype=np.float64)
+        self.gw = np.full(self.dm_state, 1e1) if gw is None else np.asarray(gw, dtype=np.float64)
+        self.uw = np.full(self.dm_act, 1e0) if uw is None else np.asarray(uw, dtype=np.float64)
+        self.umax, self.xmax = np.inf, np.full(self.dm_state, np.inf)
+        self.x0 = np.full(self.dm_state, 5.) if x0 is None else np.asarray(x0, dtype=np.float64)
+        self.sigma, self.sigma0 = 1e-8 * np.eye(self.dm_state), 1e-2 * np.eye(self.dm_state)
+        super().__init__()
+
+    def _fill_linear(self, e):
+        n, m = self.dm_state, self.dm_act
+        for k, v in enumerate(np.asarray(self.A).flatten(order="F")):
+            e.lin_A[k] = float(v)
+        for k, v in enumerate(np.asarray(self.B).flatten(order="F")):
+            e.lin_B[k] = float(v)
+        for k, v in enumerate(np.asarray(self.c).reshape(n)):
+            e.lin_c[k] = float(v)
+
+
+class Quadrotor(Env):
+    """Build-defined 12-state rigid body with 4 rotor thrusts (BASELINE config C4).  NOT in the reference:
+    its nearest env is QuadPendulum (dx=8, du=4).  x = [p(3), roll/pitch/yaw, v(3), body rates], u = thrusts."""
+    model = ENV_QUADROTOR
+    phys = (9.81, 0.5, 0.25, 3.9e-3, 3.9e-3, 7.5e-3, 1.6e-2)  # g, mass, arm, Ixx, Iyy, Izz, kM
+
+    def __init__(self):
+        self.dm_state, self.dm_act, self.dt = 12, 4, 0.01
+        self.sigma = 1e-8 * np.eye(12)
+        self.g = np.array([1., 1., 1.] + [0.] * 9)
+        self.gw = np.array([1e1] * 3 + [1e0] * 3 + [1e0] * 3 + [1e-1] * 3)
+        self.xmax = np.full(12, np.inf)
+        self.uw, self.umax = 1e-3 * np.ones(4), 5. * np.ones(4)
+        self.x0, self.sigma0 = np.zeros(12), 1e-4 * np.eye(12)
+        super().__init__()
+
+
+_REGISTRY = {
+    # the reference's gym ids (/root/reference/trajopt/__init__.py:3-97) for the envs in scope
+    "Pendulum-TO-v0": Pendulum, "Cartpole-TO-v0": Cartpole, "DoubleCartpole-TO-v0": DoubleCartpole,
+    "LQR-TO-v0": LQRv0,
+    "pendulum": Pendulum, "cartpole": Cartpole, "double_cartpole": DoubleCartpole, "lqr": LQRv0,
+    "quadrotor": Quadrotor, "Quadrotor-TO-v0": Quadrotor,
+}
+
+
+def make(name, dt=None, uw=None, slew_rate=None, periodic=None, **kw):
+    """gym.make stand-in: `make('Cartpole-TO-v0')`; keyword overrides are set as attributes afterwards,
+    the way the reference's scripts do (examples/ilqr/mpc/pendulum.py:12-13)."""
+    if name not in _REGISTRY:
+        raise KeyError("unknown env %r (in scope: %s)" % (name, sorted(_REGISTRY)))
+    env = _REGISTRY[name](**kw)
+    if dt is not None:
+        env.dt = float(dt)
+    if uw is not None:
+        env.uw = np.asarray(uw, dtype=np.float64) * np.ones(env.dm_act)
+    if slew_rate is not None:
+        env.slew_rate = bool(slew_rate)
+    if periodic is not None:
+        env.periodic = bool(periodic)
+    return env

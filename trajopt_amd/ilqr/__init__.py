@@ -1,0 +1,2 @@
+"""Mirror of the reference package `trajopt.ilqr` (/root/reference/trajopt/ilqr/__init__.py exports iLQR)."""
+from .ilqr import BatchedILQR, iLQR  # noqa: F401

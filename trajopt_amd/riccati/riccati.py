@@ -1,0 +1,131 @@
+"""Time-varying LQR solvers.
+
+`Riccati`        - the reference's class (/root/reference/trajopt/riccati/riccati.py:8-161), one problem.
+`BatchedRiccati` - the backward sweep (riccati.py:100-126) for N problems with caller-supplied
+                   quadratic/affine models resident on the GPU (BASELINE config C5).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from .._lib import check, lib
+from ..backward import riccati_backward_pass
+from ..ilqr.ilqr import make_weighting
+from .objects import AnalyticalLinearDynamics, AnalyticalQuadraticCost, LinearControl, QuadraticStateValue
+
+
+def _in(a, shape, name):
+    a = np.asfortranarray(np.asarray(a, dtype=np.float64))
+    if a.shape != shape:
+        raise ValueError("%s has shape %s, expected %s" % (name, a.shape, shape))
+    return a
+
+
+def backward_pass_host(Cxx, cx, Cuu, cu, Cxu, A, B, c, dm_state, dm_act, nb_steps):
+    """riccati.py:100-126 on host arrays in the reference layout -> (K, kff, V, v); runs the HIP kernel.
+    Raises numpy.linalg.LinAlgError where np.linalg.inv (riccati.py:118) would."""
+    _lib.require_gpu()
+    n, m, T = int(dm_state), int(dm_act), int(nb_steps)
+    Cxx = _in(Cxx, (n, n, T + 1), "Cxx"); cx = _in(cx, (n, T + 1), "cx")
+    Cuu = _in(Cuu, (m, m, T + 1), "Cuu"); cu = _in(cu, (m, T + 1), "cu")
+    Cxu = _in(Cxu, (n, m, T + 1), "Cxu"); A = _in(A, (n, n, T), "A"); B = _in(B, (n, m, T), "B")
+    c = _in(c, (n, T), "c")
+    z = lambda *s: np.zeros(s, order="F")
+    V, v, K, kff = z(n, n, T + 1), z(n, T + 1), z(m, n, T), z(m, T)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    status = C.c_int(0)
+    check(lib().trajopt_riccati_backward_pass_host(p(Cxx), p(cx), p(Cuu), p(cu), p(Cxu), p(A), p(B), p(c), n, m, T,
+                                                   p(V), p(v), p(K), p(kff), C.byref(status)))
+    if status.value != 0:
+        raise np.linalg.LinAlgError("Singular matrix (Quu at step %d)" % (status.value - 1))
+    return K, kff, V, v
+
+
+class Riccati:
+    """Drop-in for trajopt.riccati.Riccati (riccati.py:8-161).  One deliberate deviation: V = Qxx + Qux^T K
+    is the matrix product (riccati.py:123 writes an elementwise `*`, which only coincides for dm_act == 1 and
+    raises a broadcast error otherwise)."""
+
+    def __init__(self, env, nb_steps, init_state, activation=None):
+        self.env = env
+        self.env_dyn = self.env.unwrapped.dynamics
+        self.env_noise = self.env.unwrapped.sigma
+        self.env_cost = self.env.unwrapped.cost
+        self.env_init = init_state
+        self.ulim = self.env.action_space.high
+        self.dm_state = self.env.observation_space.shape[0]
+        self.dm_act = self.env.action_space.shape[0]
+        self.nb_steps = nb_steps
+
+        self.xref = np.zeros((self.dm_state, self.nb_steps + 1))
+        self.xref[..., 0] = self.env_init[0]
+        self.uref = np.zeros((self.dm_act, self.nb_steps))
+
+        self.vfunc = QuadraticStateValue(self.dm_state, self.nb_steps + 1)
+        self.dyn = AnalyticalLinearDynamics(self.env_dyn, self.dm_state, self.dm_act, self.nb_steps)
+        self.ctl = LinearControl(self.dm_state, self.dm_act, self.nb_steps)
+        self.weighting = make_weighting(self.nb_steps, activation)
+        self.cost = AnalyticalQuadraticCost(self.env_cost, self.dm_state, self.dm_act, self.nb_steps + 1)
+
+    def rollout(self, nb_episodes, env=None):  # riccati.py:52-83
+        if env is None:
+            env, env_cost = self.env, self.env_cost
+        else:
+            env_cost = env.unwrapped.cost
+        data = {'x': np.zeros((self.dm_state, self.nb_steps, nb_episodes)),
+                'u': np.zeros((self.dm_act, self.nb_steps, nb_episodes)),
+                'xn': np.zeros((self.dm_state, self.nb_steps, nb_episodes)),
+                'c': np.zeros((self.nb_steps + 1, nb_episodes))}
+        for n in range(nb_episodes):
+            x = env.reset()
+            for t in range(self.nb_steps):
+                u = self.ctl.action(x, t)
+                data['u'][..., t, n] = u
+                data['c'][t] = env_cost(x, u, data['u'][..., t - 1, n], self.weighting[t])
+                data['x'][..., t, n] = x
+                x, _, _, _ = env.step(u)
+                data['xn'][..., t, n] = x
+            data['c'][-1, n] = env_cost(x, np.zeros((self.dm_act,)), np.zeros((self.dm_act,)), self.weighting[-1])
+        return data
+
+    def forward_pass(self, ctl):  # riccati.py:85-98: on the NOISY env (env.reset / env.step)
+        state = np.zeros((self.dm_state, self.nb_steps + 1))
+        action = np.zeros((self.dm_act, self.nb_steps))
+        cost = np.zeros((self.nb_steps + 1,))
+        state[..., 0] = self.env.reset()
+        for t in range(self.nb_steps):
+            action[..., t] = ctl.action(state[..., t], t)
+            cost[..., t] = self.env_cost(state[..., t], action[..., t], action[..., t - 1], self.weighting[t])
+            state[..., t + 1], _, _, _ = self.env.step(action[..., t])
+        cost[..., -1] = self.env_cost(state[..., -1], np.zeros((self.dm_act,)), np.zeros((self.dm_act,)),
+                                      self.weighting[-1])
+        return state, action, cost
+
+    def backward_pass(self):  # riccati.py:100-126
+        lc = LinearControl(self.dm_state, self.dm_act, self.nb_steps)
+        xvalue = QuadraticStateValue(self.dm_state, self.nb_steps + 1)
+        lc.K, lc.kff, xvalue.V, xvalue.v = backward_pass_host(
+            self.cost.Cxx, self.cost.cx, self.cost.Cuu, self.cost.cu, self.cost.Cxu, self.dyn.A, self.dyn.B,
+            self.dyn.c, self.dm_state, self.dm_act, self.nb_steps)
+        return lc, xvalue
+
+    def run(self):  # riccati.py:148-161
+        self.dyn.taylor_expansion(self.xref, self.uref)
+        self.cost.taylor_expansion(self.xref, self.uref, self.weighting)
+        self.ctl, self.vfunc = self.backward_pass()
+        self.xref, self.uref, _cost = self.forward_pass(self.ctl)
+        return np.sum(_cost)
+
+
+class BatchedRiccati:
+    """Backward sweep for N problems given device tensors (layout per trajopt_amd.layout) of
+    Cxx, cx, Cuu, cu, Cxu (T+1 slices) and A, B, c (T slices)."""
+
+    def __init__(self, dm_state, dm_act, nb_steps, nb_problems, layout=_lib.LAYOUT_PROBLEM_MAJOR):
+        self.dm_state, self.dm_act, self.nb_steps, self.nb_problems = dm_state, dm_act, nb_steps, nb_problems
+        self.layout = layout
+
+    def backward_pass(self, Cxx, cx, Cuu, cu, Cxu, A, B, c):
+        return riccati_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, c, self.dm_state, self.dm_act, self.nb_steps,
+                                     self.nb_problems, self.layout)
