@@ -243,8 +243,9 @@ class Env:
             B[:, j] = self.dynamics(x.astype(complex), up).imag / h
         return A, B
 
-    def cost_derivatives_fd(self, x, u, u_last, a, h=1e-3):
-        """Central differences of the literal cost; exact (to round-off) because the cost is quadratic."""
+    def cost_derivatives_fd(self, x, u, u_last, a, h=1.0):
+        """Central differences of the literal cost; exact for any h because the cost is quadratic, and h = 1
+        keeps the round-off of the second differences at the 1e-16 relative level."""
         x, u, u_last = np.asarray(x, dtype=float), np.atleast_1d(u).astype(float), np.atleast_1d(u_last).astype(float)
         z0 = np.concatenate([x, u])
         n, m = self.n, self.m

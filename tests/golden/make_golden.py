@@ -1,0 +1,100 @@
+"""Generates the golden fixtures in this directory.  PARITY UNPINNED: the reference ships no tests or
+fixtures and neither its native core (Armadillo + OpenBLAS) nor its Python (autograd, gym) can run in the
+build image, so these vectors come from the CPU oracle (oracle/liboracle.so, a restatement of
+/root/reference/trajopt/ilqr/src/util.cpp:83-182, riccati/riccati.py:100-126, ilqr/ilqr.py:89-237 and the env
+files), and are only written after two independent implementations agree on them:
+  * the NumPy mirror (oracle/numpy_mirror.py; complex-step Jacobians, np.linalg.inv) within 1e-10, and
+  * the x87 long-double build of the same recursion within 1e-11.
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import numpy_mirror as M  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from trajopt_amd import synthetic as S  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = ("Qxx", "Qux", "Quu", "qx", "qu", "V", "v", "dV", "K", "kff")
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300))
+
+
+def backward_case(name, n, m, T, lmbda, reg, seed):
+    q = S.problem(S.backward_inputs(n, m, T, 1, seed=seed), 0)
+    args = [q[k] for k in ("Cxx", "cx", "Cuu", "cu", "Cxu", "A", "B")]
+    ref, failed = O.backward_pass(*args, lmbda, reg, n, m, T)
+    ld, _ = O.backward_pass(*args, lmbda, reg, n, m, T, long_double=True)
+    mir, mfailed = M.backward_pass(*args, lmbda, reg, n, m, T)
+    assert not failed and not mfailed
+    for k, a, b, c in zip(OUT, ref[:10], ld[:10], mir[:10]):
+        assert rel(a, b) < 1e-11, (name, k, rel(a, b))
+        assert rel(a, c) < 1e-10, (name, k, rel(a, c))
+    d = {"in_" + k: v for k, v in q.items()}
+    d.update({"out_" + k: v for k, v in zip(OUT, ref[:10])})
+    d.update(lmbda=lmbda, reg=reg, n=n, m=m, T=T)
+    np.savez(os.path.join(HERE, name + ".npz"), **d)
+
+
+def riccati_case(name, n, m, T, seed):
+    q = S.problem(S.backward_inputs(n, m, T, 1, seed=seed, affine=True), 0)
+    args = [q[k] for k in ("Cxx", "cx", "Cuu", "cu", "Cxu", "A", "B", "c")]
+    K, kff, V, v = O.riccati_backward_pass(*args, n, m, T)
+    ld = O.riccati_backward_pass(*args, n, m, T, long_double=True)
+    mir = M.riccati_backward_pass(*args, n, m, T)
+    for k, a, b, c in zip(("K", "kff", "V", "v"), (K, kff, V, v), ld, mir):
+        assert rel(a, b) < 1e-11 and rel(a, c) < 1e-10, (name, k, rel(a, b), rel(a, c))
+    d = {"in_" + k: v_ for k, v_ in q.items()}
+    d.update(out_K=K, out_kff=kff, out_V=V, out_v=v, n=n, m=m, T=T)
+    np.savez(os.path.join(HERE, name + ".npz"), **d)
+
+
+def ilqr_case(name, env_name, T, iters, seed, **kw):
+    oe = O.make_env(env_name, **kw)
+    me = M.Env(env_name, dt=kw.get("dt"), uw=kw.get("uw"))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n, m = oe.dm_state, oe.dm_act
+    x0 = {"pendulum": np.array([np.pi, 0.]), "cartpole": np.array([0., np.pi, 0., 0.])}[env_name] \
+        + 1e-2 * rng.standard_normal(n)
+    kff0 = 1e-4 * rng.standard_normal((m, T))
+    r = O.ilqr_run(oe, T, x0, kff0, nb_iter=iters)
+    mr = M.ilqr_run(me, T, x0, kff0, np.ones(T + 1), O.DEFAULT_ALPHAS, iters)
+    assert len(r["trace"]) == len(mr["trace"]) and rel(r["trace"], mr["trace"]) < 1e-9, (r["trace"], mr["trace"])
+    assert rel(r["xref"], mr["xref"]) < 1e-7 and rel(r["K"], mr["K"]) < 1e-6
+    # one env step, one rollout and one quadratisation along the solution, for the kernels in isolation
+    w = np.ones(T + 1)
+    q = O.quadratize(oe, T, r["xref"], r["uref"], w)
+    mq = M.quadratize(me, T, r["xref"], r["uref"], w)
+    for k in ("A", "B", "Cxx", "cx", "Cuu", "cu", "Cxu"):
+        assert np.max(np.abs(q[k] - mq[k])) < 1e-6 * max(1.0, np.max(np.abs(mq[k]))), (k,)
+    st, ac, co = O.forward_pass(oe, T, x0, r["K"], r["kff"], 0.5, r["xref"], r["uref"], w)
+    mst, mac, mco = M.forward_pass(me, T, x0, r["K"], r["kff"], 0.5, r["xref"], r["uref"], w)
+    assert rel(st, mst) < 1e-9 and rel(co, mco) < 1e-9
+    d = dict(x0=x0, kff0=kff0, iters=iters, T=T, dt=kw.get("dt"), uw=np.asarray(kw.get("uw")),
+             trace=r["trace"], xref=r["xref"], uref=r["uref"], K=r["K"], kff=r["kff"], V=r["V"], v=r["v"],
+             lmbda=r["lmbda"], dlmbda=r["dlmbda"], status=r["status"], alpha=r["alpha"],
+             fp_state=st, fp_action=ac, fp_cost=co, fp_alpha=0.5)
+    d.update({"q_" + k: v for k, v in q.items() if k != "c"})
+    np.savez(os.path.join(HERE, name + ".npz"), **d)
+
+
+if __name__ == "__main__":
+    backward_case("bwd_c1_pendulum_2x1_T100", 2, 1, 100, 1.0, 1, 1337)
+    backward_case("bwd_c2_cartpole_4x1_T64", 4, 1, 64, 1.0, 1, 1338)
+    backward_case("bwd_c3_dcartpole_6x1_T64", 6, 1, 64, 1.0, 1, 1339)
+    backward_case("bwd_c4_quadrotor_12x4_T32", 12, 4, 32, 1.0, 1, 1340)
+    backward_case("bwd_reg2_4x2_T24", 4, 2, 24, 0.5, 2, 1341)
+    riccati_case("ric_c5_64x16_T2", 64, 16, 2, 1342)
+    riccati_case("ric_6x2_T40", 6, 2, 40, 1343)
+    ilqr_case("ilqr_pendulum_T40", "pendulum", 40, 6, 1344, dt=0.05, uw=[1e-5])
+    ilqr_case("ilqr_cartpole_T30", "cartpole", 30, 4, 1345, dt=0.02, uw=[1e-5])
+    print("golden fixtures written to", HERE)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print("  %-36s %7d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

@@ -1,0 +1,238 @@
+"""The oracle is pinned by analytic known answers, by an independent NumPy mirror and by a long-double
+build (the reference has no tests, so parity is otherwise unpinned).  CPU only."""
+import numpy as np
+import pytest
+import scipy.linalg
+
+from tests.util import assert_close, rel_err
+from trajopt_amd import synthetic as S
+
+OUT = ("Qxx", "Qux", "Quu", "qx", "qu", "V", "v", "dV", "K", "kff")
+KEYS = ("Cxx", "cx", "Cuu", "cu", "Cxu", "A", "B")
+
+
+def lti_problem(T, dt=0.1, gw=(1e1, 1e1), uw=(1e0,)):
+    """LQR-TO-v0 (/root/reference/trajopt/envs/lqr/lqr_v0.py:14-24) in the iLQR convention (objects.py:74-78)."""
+    A0, B0 = np.array([[1.1, 0.], [1.0, 1.0]]), np.array([[1.], [0.]])
+    n, m = 2, 1
+    z = lambda *s: np.zeros(s, order="F")
+    A, B = z(n, n, T), z(n, m, T)
+    Cxx, cx, Cuu, cu, Cxu = z(n, n, T + 1), z(n, T + 1), z(m, m, T + 1), z(m, T + 1), z(n, m, T + 1)
+    A[:] = A0[:, :, None]; B[:] = B0[:, :, None]
+    Cxx[:] = (2 * dt * np.diag(gw))[:, :, None]
+    Cuu[:, :, :T] = (2 * dt * np.diag(uw))[:, :, None]
+    return (Cxx, cx, Cuu, cu, Cxu, A, B), A0, B0, dt * np.diag(gw), dt * np.diag(uw)
+
+
+def test_dare_fixed_point(oracle):
+    """(i) long horizon, lmbda = 0: K_0 -> -(R + B'PB)^-1 B'PA and V_0 -> 2P."""
+    args, A0, B0, Q, R = lti_problem(200)
+    out, failed = oracle.backward_pass(*args, 0.0, 1, 2, 1, 200)
+    assert not failed
+    P = scipy.linalg.solve_discrete_are(A0, B0, Q, R)
+    Kinf = -np.linalg.solve(R + B0.T @ P @ B0, B0.T @ P @ A0)
+    np.testing.assert_allclose(out[8][..., 0], Kinf, rtol=1e-9)
+    np.testing.assert_allclose(out[5][..., 0], 2 * P, rtol=1e-8)
+
+
+@pytest.mark.parametrize("n,m", [(2, 1), (4, 1), (6, 1), (12, 4)])
+def test_schur_identity_and_q_blocks(oracle, n, m):
+    """(ii) at lmbda = 0 the long form of util.cpp:159-160 equals Qxx - Qux' Quu^-1 Qux; qfunc blocks by definition."""
+    T = 12
+    q = S.problem(S.backward_inputs(n, m, T, 1, seed=9), 0)
+    out, failed = oracle.backward_pass(*[q[k] for k in KEYS], 0.0, 1, n, m, T)
+    assert not failed
+    Qxx, Qux, Quu, qx, qu, V, v, dV, K, kff = out[:10]
+    for t in range(T):
+        a, b, Vn, vn = q["A"][..., t], q["B"][..., t], V[..., t + 1], v[..., t + 1]
+        np.testing.assert_allclose(Qxx[..., t], q["Cxx"][..., t] + a.T @ Vn @ a, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(Qux[..., t], (q["Cxu"][..., t] + a.T @ Vn @ b).T, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(qu[..., t], q["cu"][..., t] + b.T @ vn, rtol=1e-12, atol=1e-13)
+        S_ = Qxx[..., t] - Qux[..., t].T @ np.linalg.solve(Quu[..., t], Qux[..., t])
+        np.testing.assert_allclose(V[..., t], 0.5 * (S_ + S_.T), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(v[..., t], qx[..., t] - Qux[..., t].T @ np.linalg.solve(Quu[..., t], qu[..., t]),
+                                   rtol=1e-9, atol=1e-11)
+        assert np.array_equal(V[..., t], V[..., t].T)  # util.cpp:161
+
+
+def test_expected_reduction_is_exact_on_an_lq_problem(oracle):
+    """(iii) LQ problem, lmbda = 0, alpha = 1: the cost drop of the first iteration is -(dV0 + dV1)."""
+    e = oracle.make_env("lqr")
+    T = 25
+    x0 = np.array([5., 5.]) + np.array([0.3, -0.2])
+    w = np.ones(T + 1)
+    st, ac, co = oracle.forward_pass(e, T, x0, np.zeros((1, 2, T)), np.zeros((1, T)), 1.0, np.zeros((2, T + 1)),
+                                     np.zeros((1, T)), w)
+    q = oracle.quadratize(e, T, st, ac, w)
+    out, failed = oracle.backward_pass(*[q[k] for k in KEYS], 0.0, 1, 2, 1, T)
+    st2, ac2, co2 = oracle.forward_pass(e, T, x0, out[8], out[9], 1.0, st, ac, w)
+    assert (co.sum() - co2.sum()) == pytest.approx(-(out[7][0] + out[7][1]), rel=1e-9)
+    # and the new trajectory is optimal: another backward pass gives a zero feed-forward
+    q2 = oracle.quadratize(e, T, st2, ac2, w)
+    out2, _ = oracle.backward_pass(*[q2[k] for k in KEYS], 0.0, 1, 2, 1, T)
+    assert np.max(np.abs(out2[9])) < 1e-9 * max(1.0, np.max(np.abs(ac2)))
+
+
+def test_riccati_convention_agrees_with_ilqr_convention_on_lq(oracle):
+    """(iv) the "no-1/2, affine-c" sweep (riccati.py:100-126) on the Riccati expansion gives the same feedback
+    gains as util.cpp on the iLQR expansion, V_riccati = V_ilqr / 2, and u = kff + K x reproduces the iLQR step."""
+    e = oracle.make_env("lqr")
+    T = 20
+    w = np.ones(T + 1)
+    xref, uref = np.zeros((2, T + 1)), np.zeros((1, T))
+    qi = oracle.quadratize(e, T, xref, uref, w)
+    qr = oracle.quadratize(e, T, xref, uref, w, riccati=True)
+    oi, _ = oracle.backward_pass(*[qi[k] for k in KEYS], 0.0, 1, 2, 1, T)
+    K, kff, V, v = oracle.riccati_backward_pass(*[qr[k] for k in KEYS], qr["c"], 2, 1, T)
+    assert_close(K, oi[8], "K")
+    assert_close(V, 0.5 * oi[5], "V")
+
+
+@pytest.mark.parametrize("n,m", [(2, 1), (4, 2), (12, 4)])
+def test_divergence_is_reported_at_the_failing_step_and_lambda_clears_it(oracle, n, m):
+    """(v) util.cpp:145-148 and the retry loop ilqr.py:162-173."""
+    T, at = 20, 7
+    q = S.problem(S.backward_inputs(n, m, T, 1, seed=2), 0)
+    q["Cuu"][..., at] = -50.0 * np.eye(m)
+    out, failed = oracle.backward_pass(*[q[k] for k in KEYS], 1e-3, 1, n, m, T)
+    assert failed and out[10] == at
+    assert not np.any(out[8][..., :at + 1]) and np.any(out[8][..., at + 1:])
+    out, failed = oracle.backward_pass(*[q[k] for k in KEYS], 60.0, 1, n, m, T)
+    assert not failed and out[10] == 0
+    # a failure AT t = 0 is "0" in the reference's int (quirk 2) but flagged here
+    q = S.problem(S.backward_inputs(n, m, T, 1, seed=2), 0)
+    q["Cuu"][..., 0] = -50.0 * np.eye(m)
+    out, failed = oracle.backward_pass(*[q[k] for k in KEYS], 1e-3, 1, n, m, T)
+    assert failed and out[10] == 0
+
+
+def test_reg_modes(oracle, mirror):
+    """(vi) reg == 2 regularises V' (util.cpp:135-141), reg == 1 regularises Quu (:142-143), other = none."""
+    n, m, T = 4, 2, 15
+    q = S.problem(S.backward_inputs(n, m, T, 1, seed=4), 0)
+    args = [q[k] for k in KEYS]
+    o0, _ = oracle.backward_pass(*args, 0.0, 1, n, m, T)
+    o0b, _ = oracle.backward_pass(*args, 0.0, 2, n, m, T)
+    o3, _ = oracle.backward_pass(*args, 7.0, 3, n, m, T)
+    for a, b, c in zip(o0[:10], o0b[:10], o3[:10]):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    o1, _ = oracle.backward_pass(*args, 0.7, 1, n, m, T)
+    o2, _ = oracle.backward_pass(*args, 0.7, 2, n, m, T)
+    assert rel_err(o1[8], o2[8]) > 1e-3
+    for reg, o in ((1, o1), (2, o2)):
+        ref, _ = mirror.backward_pass(*args, 0.7, reg, n, m, T)
+        for k, a, b in zip(OUT, o[:10], ref[:10]):
+            assert_close(a, b, "reg%d %s" % (reg, k), tol=1e-11)
+    # one step by hand for reg == 2
+    t = T - 1
+    a, b, Vn = q["A"][..., t], q["B"][..., t], q["Cxx"][..., T]
+    Vr = Vn + 0.7 * np.eye(n)
+    Kt = -np.linalg.solve(q["Cuu"][..., t] + b.T @ Vr @ b, (q["Cxu"][..., t] + a.T @ Vr @ b).T)
+    np.testing.assert_allclose(o2[8][..., t], Kt, rtol=1e-12)
+
+
+@pytest.mark.parametrize("n,m,T", [(2, 1, 100), (4, 1, 120), (6, 1, 80), (12, 4, 40), (16, 4, 10)])
+def test_cpp_oracle_vs_numpy_mirror_vs_long_double(oracle, mirror, n, m, T):
+    """(vii) three implementations of util.cpp:83-182 agree far inside the 1e-9 bar."""
+    q = S.problem(S.backward_inputs(n, m, T, 1, seed=100 + n), 0)
+    args = [q[k] for k in KEYS]
+    o, f = oracle.backward_pass(*args, 1.0, 1, n, m, T)
+    ld, _ = oracle.backward_pass(*args, 1.0, 1, n, m, T, long_double=True)
+    mi, _ = mirror.backward_pass(*args, 1.0, 1, n, m, T)
+    assert not f
+    for k, a, b, c in zip(OUT, o[:10], ld[:10], mi[:10]):
+        assert_close(a, b, "ld " + k, tol=1e-11)
+        assert_close(a, c, "mirror " + k, tol=1e-10)
+
+
+@pytest.mark.parametrize("n,m,T", [(2, 1, 50), (6, 2, 30), (16, 4, 8)])
+def test_riccati_oracle_vs_mirror(oracle, mirror, n, m, T):
+    q = S.problem(S.backward_inputs(n, m, T, 1, seed=55, affine=True), 0)
+    args = [q[k] for k in KEYS] + [q["c"]]
+    got = oracle.riccati_backward_pass(*args, n, m, T)
+    ref = mirror.riccati_backward_pass(*args, n, m, T)
+    for k, a, b in zip(("K", "kff", "V", "v"), got, ref):
+        assert_close(a, b, k, tol=1e-10)
+    if m == 1:  # the reference's literal elementwise `*` (riccati.py:123) coincides for one action dim
+        lit = oracle.riccati_backward_pass(*args, n, m, T, literal_elementwise=True)
+        for a, b in zip(got, lit):
+            assert_close(a, b, "literal", tol=1e-12)
+
+
+def test_is_sympd_rule(oracle, mirror):
+    """Armadillo's tolerance rule as restated: m == 1 reduces to q > 100 eps |q|."""
+    assert mirror.arma_is_sympd(np.array([[1e-300]]))
+    assert not mirror.arma_is_sympd(np.array([[0.0]])) and not mirror.arma_is_sympd(np.array([[-1.0]]))
+    assert not mirror.arma_is_sympd(np.array([[np.nan]]))
+    X = np.array([[2.0, 1.0], [1.0 + 1e-9, 2.0]])      # asymmetric beyond tolerance
+    assert not mirror.arma_is_sympd(X)
+    assert mirror.arma_is_sympd(np.array([[2.0, 1.0], [1.0, 2.0]]))
+    assert not mirror.arma_is_sympd(np.array([[1.0, 2.0], [2.0, 1.0]]))  # indefinite
+    # the C++ oracle applies the same rule through the divergence flag
+    n, m, T = 2, 2, 1
+    z = lambda *s: np.zeros(s, order="F")
+    Cuu = z(m, m, T + 1); Cuu[..., 0] = X
+    o, failed = oracle.backward_pass(np.zeros((n, n, T + 1)), z(n, T + 1), Cuu, z(m, T + 1), z(n, m, T + 1),
+                                     z(n, n, T), z(n, m, T), 0.0, 1, n, m, T)
+    assert failed
+
+
+ENVS = [("pendulum", dict(dt=0.05)), ("cartpole", dict(dt=0.02)), ("double_cartpole", dict()), ("quadrotor", dict()),
+        ("lqr", dict())]
+
+
+@pytest.mark.parametrize("name,kw", ENVS)
+def test_env_models_and_derivatives_vs_mirror(oracle, mirror, name, kw):
+    """Dual-number Jacobians (the autograd stand-in) vs complex-step; dynamics and cost vs the NumPy restatement."""
+    e, me = oracle.make_env(name, **kw), mirror.Env(name, **kw)
+    rng = np.random.default_rng(8)
+    for trial in range(12):
+        x = rng.standard_normal(me.n)
+        if name == "quadrotor":
+            x[3:6] *= 0.3
+        u = 3.0 * rng.standard_normal(me.m) if trial % 3 else 20.0 * np.ones(me.m)  # saturated every 3rd
+        ul = rng.standard_normal(me.m)
+        np.testing.assert_allclose(oracle.env_dynamics(e, x, u), me.dynamics(x, u), rtol=1e-12, atol=1e-13)
+        assert oracle.env_cost(e, x, u, ul, 0.7) == pytest.approx(me.cost(x, u, ul, 0.7), rel=1e-12)
+        assert oracle.env_cost(e, x, u, ul, 0.0) == pytest.approx(me.cost(x, u, ul, 0.0), rel=1e-12)
+        A, B = oracle.env_jacobians(e, x, u)
+        mA, mB = me.jacobians(x, u)
+        np.testing.assert_allclose(A, mA, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(B, mB, rtol=1e-10, atol=1e-12)
+        if trial % 3 == 0 and name != "lqr":
+            assert not np.any(B)  # quirk 10: clip derivative is 0 on the bound
+
+
+def test_slew_and_periodic_cost_derivatives(oracle, mirror):
+    e = oracle.make_env("cartpole", slew_rate=True, periodic=True, uw=[1.0])   # uw = 1 keeps the FD check meaningful
+    me = mirror.Env("cartpole", slew_rate=True, periodic=True, uw=[1.0])
+    T = 6
+    rng = np.random.default_rng(1)
+    xref = rng.standard_normal((4, T + 1)); xref[1] += 2.0
+    uref = rng.standard_normal((1, T))
+    w = np.array([1., 0.5, 0., 2., 1., 1., 0.3])
+    q = oracle.quadratize(e, T, xref, uref, w)
+    upad = np.hstack([uref, np.zeros((1, 1))])
+    for t in range(T + 1):
+        Cxx, cx, Cuu, cu, Cxu = me.cost_derivatives_fd(xref[:, t], upad[:, t], upad[:, t - 1], w[t], h=1e-2)
+        np.testing.assert_allclose(q["Cxx"][..., t], Cxx, rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(q["cx"][..., t], cx, rtol=1e-7, atol=1e-6)
+        np.testing.assert_allclose(q["cu"][..., t], cu, rtol=1e-7, atol=1e-6)
+        np.testing.assert_allclose(q["Cuu"][..., t], Cuu, rtol=1e-6, atol=1e-5)
+    assert not np.any(q["Cxx"][..., 2]) and not np.any(q["cx"][..., 2])   # weight exactly 0 (quirk 11)
+
+
+@pytest.mark.parametrize("name,T,iters,kw", [("pendulum", 30, 6, dict(dt=0.05, uw=[1e-5])),
+                                              ("lqr", 20, 4, dict())])
+def test_ilqr_driver_vs_mirror(oracle, mirror, name, T, iters, kw):
+    e, me = oracle.make_env(name, **kw), mirror.Env(name, dt=kw.get("dt"), uw=kw.get("uw"))
+    rng = np.random.default_rng(3)
+    x0 = {"pendulum": np.array([np.pi, 0.]), "lqr": np.array([5., 5.])}[name] + 1e-2 * rng.standard_normal(me.n)
+    kff0 = 1e-4 * rng.standard_normal((me.m, T))
+    r = oracle.ilqr_run(e, T, x0, kff0, nb_iter=iters)
+    mr = mirror.ilqr_run(me, T, x0, kff0, np.ones(T + 1), oracle.DEFAULT_ALPHAS, iters)
+    assert len(r["trace"]) == len(mr["trace"]) and r["status"] == mr["status"]
+    assert_close(r["trace"], mr["trace"], "trace")
+    assert r["lmbda"] == pytest.approx(mr["lmbda"], rel=1e-12)
+    assert_close(r["xref"], mr["xref"], "xref", tol=1e-7)
+    assert r["trace"][-1] < r["trace"][0]
