@@ -1,0 +1,89 @@
+"""Microbenchmark of the batched backward passes alone (developer tool; bench.py is the contract).
+  --variant ilqr    : util.cpp recursion (rows A1), full and gains-only outputs
+  --variant riccati : riccati.py sweep with affine c (row A9; BASELINE config C5 at --n 64 --m 16 --T 1000 --N 1024)
+Inputs are generated on the device (SPD Cxx / Cuu by construction)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from trajopt_amd import backward  # noqa: E402
+from trajopt_amd.layout import device_shape  # noqa: E402
+
+
+def make(n, m, T, N, layout, affine, dev="cuda"):
+    g = torch.Generator(device=dev)
+    g.manual_seed(1337)
+
+    def rn(scale, *logical):
+        x = torch.randn(device_shape(logical, layout), generator=g, dtype=torch.float64, device=dev)
+        return x.mul_(scale)
+
+    def add_eye(x, k, scale):
+        I = scale * torch.eye(k, dtype=torch.float64, device=dev)
+        x += I.reshape(1, 1, k, k) if layout == 0 else I.reshape(1, k, k, 1)
+        return x
+
+    d = dict(A=add_eye(rn(0.01 / n ** 0.5, N, n, n, T), n, 1.0), B=rn(0.01, N, n, m, T),
+             Cxx=add_eye(rn(0.0, N, n, n, T + 1), n, 1.0), Cuu=add_eye(rn(0.0, N, m, m, T + 1), m, 1e-2),
+             Cxu=rn(0.01, N, n, m, T + 1), cx=rn(1.0, N, n, T + 1), cu=rn(1.0, N, m, T + 1))
+    if affine:
+        d["c"] = rn(0.01, N, n, T)
+    return d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", default="ilqr")
+    ap.add_argument("--n", type=int, default=4); ap.add_argument("--m", type=int, default=1)
+    ap.add_argument("--T", type=int, default=500); ap.add_argument("--N", type=int, default=4096)
+    ap.add_argument("--layout", type=int, default=1); ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--same-step", type=int, default=0); ap.add_argument("--lpw", type=int, default=0)
+    ap.add_argument("--force-wg", type=int, default=0)
+    a = ap.parse_args()
+    n, m, T, N = a.n, a.m, a.T, a.N
+    from trajopt_amd._lib import lib
+    lib().trajopt_debug_tpp_same_step(a.same_step)
+    lib().trajopt_debug_tpp_lpw(a.lpw)
+    lib().trajopt_debug_force_kernel(a.force_wg)
+    d = make(n, m, T, N, a.layout, a.variant == "riccati")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if a.variant == "riccati":
+        call = lambda: backward.riccati_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"],
+                                                      d["c"], n, m, T, N, a.layout)
+        o = call()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(a.reps):
+            o = call()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.reps
+        b = 8 * (3 * n * n + 3 * n * m + m * m + 4 * n + 2 * m)   # in A,B,c,Cxx,Cuu,Cxu,cx,cu; out K,kff,V,v
+        fl = 4 * n ** 3 + 10 * n * n * m + 6 * n * m * m + 2 * m ** 3 + 2 * n * n
+        print("riccati n=%d m=%d T=%d N=%d layout=%d: %.3f ms  %.1f GB/s  %.2f TFLOP/s  bad=%d finite=%s" % (
+            n, m, T, N, a.layout, ms, N * T * b / ms / 1e6, N * T * fl / ms / 1e9, int((o["status"] != 0).sum()),
+            bool(torch.isfinite(o["K"]).all())))
+        return
+    lam = torch.ones(N, dtype=torch.float64, device="cuda")
+    for full in (True, False):
+        out = {}
+        for _ in range(2):
+            backward.ilqr_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"], lam, 1, n, m, T,
+                                        N, a.layout, full=full, out=out)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(a.reps):
+            backward.ilqr_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"], lam, 1, n, m, T,
+                                        N, a.layout, full=full, out=out)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.reps
+        b = 8 * (4 * n * n + 4 * n * m + 2 * m * m + 3 * n + 3 * m) if full else \
+            8 * (2 * n * n + 3 * n * m + m * m + n + 2 * m)
+        print("ilqr n=%d m=%d T=%d N=%d layout=%d full=%d: %.3f ms  %.1f GB/s  (%.2f G problem-steps/s) diverged=%d" % (
+            n, m, T, N, a.layout, full, ms, N * T * b / ms / 1e6, N * T / ms / 1e6, int((out["diverge"] >= 0).sum())))
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,7 @@ void set_hip_error(hipError_t e, const char* where) {
 }
 
 extern int g_tpp_dbg_same_step;
+extern int g_tpp_lpw;
 static int g_force_kernel = 0;  // 0 auto, 1 always the workgroup-per-problem kernel (tests)
 
 template <bool TO_MINOR>
@@ -71,6 +72,11 @@ int trajopt_device_count(void) {
 
 int trajopt_debug_force_kernel(int which) {
     g_force_kernel = which;
+    return TRAJOPT_OK;
+}
+
+int trajopt_debug_tpp_lpw(int lpw) {
+    g_tpp_lpw = lpw;
     return TRAJOPT_OK;
 }
 

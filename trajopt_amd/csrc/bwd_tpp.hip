@@ -22,6 +22,7 @@ struct TppArgs {
     trajopt_lambda_schedule_t sched;
     size_t NP;
     int T, reg, retry;
+    int lpw;            // problems (active lanes) per wave: 64 for big batches, fewer to spread a small batch over all CUs
     int dbg_same_step;  // developer knob: reload step T-1 every step (cache-resident inputs) to time the arithmetic
 };
 
@@ -296,10 +297,10 @@ __device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N *
 
 template <int N, int M, bool FULL, bool GN>
 __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
-    const size_t p0 = (size_t)blockIdx.x * 64;  // wave-uniform: first problem of this wave
+    const size_t p0 = (size_t)blockIdx.x * a.lpw;  // wave-uniform: first problem of this wave
     const unsigned lane = threadIdx.x;
     const size_t p = p0 + lane;
-    if (p >= a.NP) return;
+    if (lane >= (unsigned)a.lpw || p >= a.NP) return;
     if (a.io.active && a.io.active[p] == 0) return;
     const size_t NP = a.NP;
     const int T = a.T;
@@ -326,18 +327,21 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
                 if (a.io.v) store_vec<N>(UBASE(a.io.v, N, T), off, v);
             }
         }
+        // The prefetch is UNCONDITIONAL (index clamped at 0, the last one is a harmless re-load): a load block
+        // under `if (t >= 1)` makes hipcc's waitcnt pass merge a no-load path at the join and emit a near-zero
+        // vmcnt there, which waits for the prefetch just issued and exposes the whole HBM latency every step.
         StepIn<N, M> s0, s1;
         int t = T - 1;
-        if (t >= 0) load_step<N, M, GN>(s0, a, p0, off, t);
+        load_step<N, M, GN>(s0, a, p0, off, t);
         while (t >= 0) {
-            if (t >= 1) load_step<N, M, GN>(s1, a, p0, off, t - 1);
+            load_step<N, M, GN>(s1, a, p0, off, t >= 1 ? t - 1 : 0);
             if (!bwd_step<N, M, FULL, GN>(s0, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, t)) {
                 div = t;
                 break;
             }
             --t;
             if (t < 0) break;
-            if (t >= 1) load_step<N, M, GN>(s0, a, p0, off, t - 1);
+            load_step<N, M, GN>(s0, a, p0, off, t >= 1 ? t - 1 : 0);
             if (!bwd_step<N, M, FULL, GN>(s1, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, t)) {
                 div = t;
                 break;
@@ -368,13 +372,22 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
 }
 
 int g_tpp_dbg_same_step = 0;
+int g_tpp_lpw = 0;  // developer knob: force the problems-per-wave choice (0 = automatic)
+
+// Problems per wave.  Measured on MI355X (C2, 4096 cartpoles, gains-only): 64 lanes 0.56 ms, 32 / 16 lanes
+// 0.67 ms, 8 lanes 0.9 ms - a wave's step costs the same ~350 fp64 issue slots whatever its active lanes and
+// more, emptier waves only add contention, so full waves win even when they cover a quarter of the CUs.
+static int pick_lpw(size_t) {
+    if (g_tpp_lpw == 8 || g_tpp_lpw == 16 || g_tpp_lpw == 32 || g_tpp_lpw == 64) return g_tpp_lpw;
+    return 64;
+}
 
 template <int N, int M>
 static int launch_nm(const TppArgs& a, hipStream_t st) {
     const bool full = a.io.Qxx || a.io.Qux || a.io.Quu || a.io.qx || a.io.qu || a.io.V || a.io.v;
     const bool gn = a.io.uref != nullptr && a.io.g_norm != nullptr;
     const dim3 block(64);
-    const dim3 grid((unsigned)((a.NP + 63) / 64));
+    const dim3 grid((unsigned)((a.NP + a.lpw - 1) / a.lpw));
     if (full) {
         if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, false>), grid, block, 0, st, a);
@@ -396,6 +409,7 @@ int launch_backward_tpp(const trajopt_backward_io_t& io, int reg, int n, int m, 
     a.reg = reg;
     a.retry = retry;
     a.dbg_same_step = g_tpp_dbg_same_step;
+    a.lpw = pick_lpw(a.NP);
     *handled = true;
     if (n == 2 && m == 1) return launch_nm<2, 1>(a, st);
     if (n == 3 && m == 1) return launch_nm<3, 1>(a, st);

@@ -15,9 +15,15 @@ int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, cons
                    const double* kff, const double* xref, const double* uref, const double* weighting,
                    const double* alphas_host, int nb_alphas, const int32_t* active, double* state, double* action,
                    double* cost, double* ret, int32_t* finite, hipStream_t st);
+struct QuadCommit {  // fused commit of the previous line search inside the quadratisation (quadratize.hip)
+    const int32_t* sel;
+    const double *cand_state, *cand_action, *cand_K, *cand_kff;
+    double *xref, *uref, *K, *kff;
+};
 int launch_quadratize(const trajopt_env_t* env, int T, int64_t NP, int layout, int convention, const double* xref,
                       const double* uref, const double* weighting, const int32_t* active, double* A, double* B,
-                      double* c, double* Cxx, double* cx, double* Cuu, double* cu, double* Cxu, hipStream_t st);
+                      double* c, double* Cxx, double* cx, double* Cuu, double* cu, double* Cxu, hipStream_t st,
+                      const QuadCommit* cm);
 
 struct DrvArgs {
     trajopt_ilqr_options_t opt;
@@ -129,10 +135,10 @@ __global__ void select_kernel(DrvArgs a) {
 __global__ void commit_kernel(DrvArgs a, int with_ctl) {
     const size_t NP = (size_t)a.ws.nb_problems;
     const int T = a.ws.nb_steps, n = a.n, m = a.m;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= NP * (size_t)(T + 1)) return;
-    const int t = (int)(idx / NP);
-    const size_t p = idx % NP;
+    // grid = (problem blocks, T + 1): no 64-bit division in the index math
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = (int)blockIdx.y;
+    if (p >= NP) return;
     const int sel = a.ws.sel[p];
     if (sel < 0) return;
     const double* st = a.ws.cand_state + (size_t)sel * (size_t)n * (T + 1) * NP;
@@ -214,8 +220,7 @@ int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_optio
     DrvArgs a{*opt, *ws, env->dm_state, env->dm_act};
     const unsigned g1 = (unsigned)((NP + 255) / 256);
     hipLaunchKernelGGL(init_select_kernel, dim3(g1), dim3(256), 0, st, a);
-    const size_t tot = (size_t)NP * (T + 1);
-    hipLaunchKernelGGL(commit_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, 0);
+    hipLaunchKernelGGL(commit_kernel, dim3(g1, (unsigned)(T + 1)), dim3(256), 0, st, a, 0);
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
 }
@@ -229,8 +234,7 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
     const int T = ws->nb_steps, n = env->dm_state, m = env->dm_act;
     DrvArgs a{*opt, *ws, n, m};
     const unsigned g1 = (unsigned)((NP + 255) / 256);
-    const size_t tot = (size_t)NP * (T + 1);
-    const unsigned g2 = (unsigned)((tot + 255) / 256);
+    const dim3 g2(g1, (unsigned)(T + 1));
     trajopt_backward_io_t io{};
     io.Cxx = ws->Cxx; io.cx = ws->cx; io.Cuu = ws->Cuu; io.cu = ws->cu; io.Cxu = ws->Cxu; io.A = ws->A; io.B = ws->B;
     io.lmbda = ws->lmbda; io.dlmbda = ws->dlmbda;
@@ -240,13 +244,20 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
     }
     io.dV = ws->dV; io.K = ws->cand_K; io.kff = ws->cand_kff; io.diverge = ws->diverge;
     io.uref = ws->uref; io.g_norm = ws->g_norm; io.active = ws->active;
+    const bool fuse_commit = !opt->keep_value;
+    const QuadCommit cm{ws->sel, ws->cand_state, ws->cand_action, ws->cand_K, ws->cand_kff,
+                        ws->xref, ws->uref, ws->K, ws->kff};
     for (int it = 0; it < nb_iter; ++it) {
         const int slot = (g_prof.on && g_prof.used < g_prof.cap) ? g_prof.used++ : -1;
         prof_mark(st, slot, 0);
         hipLaunchKernelGGL(prep_kernel, dim3(g1), dim3(256), 0, st, a);
         prof_mark(st, slot, 1);
+        // The accepted candidate of iteration it-1 is promoted to xref/uref/K/kff by this iteration's
+        // quadratisation (it reads every (problem, step) of the trajectory anyway); only the last iteration
+        // of the call, and the keep_value mode, use the stand-alone commit kernel.
         rc = launch_quadratize(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 0, ws->xref, ws->uref, ws->weighting,
-                               ws->active, ws->A, ws->B, nullptr, ws->Cxx, ws->cx, ws->Cuu, ws->cu, ws->Cxu, st);
+                               ws->active, ws->A, ws->B, nullptr, ws->Cxx, ws->cx, ws->Cuu, ws->cu, ws->Cxu, st,
+                               (fuse_commit && it > 0) ? &cm : nullptr);
         if (rc != TRAJOPT_OK) return rc;
         prof_mark(st, slot, 2);
         rc = trajopt_ilqr_backward_pass_batched(&io, opt->reg, n, m, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 1,
@@ -261,7 +272,7 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         if (rc != TRAJOPT_OK) return rc;
         prof_mark(st, slot, 5);
         hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(commit_kernel, dim3(g2), dim3(256), 0, st, a, 1);
+        if (!fuse_commit || it == nb_iter - 1) hipLaunchKernelGGL(commit_kernel, g2, dim3(256), 0, st, a, 1);
         prof_mark(st, slot, 6);
     }
     TRAJOPT_HIP_CHECK(hipGetLastError());

@@ -75,14 +75,55 @@ template <int K> __device__ __forceinline__ Dual<K> operator*(const Dual<K>& a, 
 template <int K> __device__ __forceinline__ Dual<K> operator*(double b, const Dual<K>& a) { return a * b; }
 template <int K> __device__ __forceinline__ Dual<K> operator/(const Dual<K>& a, double b) { return a * (1.0 / b); }
 
-// sin and cos together (one range reduction)
-__device__ __forceinline__ void sincos_g(double x, double& s, double& c) { sincos(x, &s, &c); }
+// sin and cos together.  fp64 issue slots are what these kernels pay for (one fp64 op per ~5 cycles per SIMD; the
+// library sincos is ~85 of them plus a Payne-Hanek path whose registers and branches sit in the hot loop).
+// Here: 3-term Cody-Waite reduction by pi/2 (k * pio2_1 is exact for |k| < 2^20: 33 + 20 bits) and the fdlibm
+// minimax kernels on |r| <= pi/4: absolute error ~1.5e-16, ~30 instructions.  Arguments beyond 2^20 (only
+// rollouts that have already blown up reach them) are first folded by 2 pi with a two-term constant, which
+// costs accuracy proportional to |x| (|x| * 2e-16) but stays finite and bounded; inf / NaN give NaN.
+__device__ __forceinline__ void sincos_g(double x, double& s, double& c) {
+    if (__builtin_expect(!(fabs(x) < 1048576.0), 0)) {
+        const double k2 = rint(x * 1.59154943091895345554e-01);       // 1 / (2 pi)
+        x = fma(-k2, 2.44929359829470641435e-16, fma(-k2, 6.28318530717958623200e+00, x));
+    }
+    const double fk = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-fk, 1.57079632673412561417e+00, x);
+    r = fma(-fk, 6.07710050630396597660e-11, r);
+    r = fma(-fk, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double sr = fma(r * z, ps, r);
+    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)fk;
+    const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
 template <int K> __device__ __forceinline__ void sincos_g(const Dual<K>& x, Dual<K>& s, Dual<K>& c) {
     double sv, cv;
-    sincos(x.v, &sv, &cv);
+    sincos_g(x.v, sv, cv);
     s.v = sv; c.v = cv;
 #pragma unroll
     for (int k = 0; k < K; ++k) { s.d[k] = cv * x.d[k]; c.d[k] = -sv * x.d[k]; }
+}
+
+// 1 / x: one division that the models reuse instead of dividing several times by the same quantity
+__device__ __forceinline__ double recip_g(double x) { return 1.0 / x; }
+template <int K> __device__ __forceinline__ Dual<K> recip_g(const Dual<K>& x) {
+    Dual<K> r; r.v = 1.0 / x.v;
+    const double m2 = -r.v * r.v;
+#pragma unroll
+    for (int k = 0; k < K; ++k) r.d[k] = m2 * x.d[k];
+    return r;
 }
 
 // np.clip(x, -lim, lim); derivative follows autograd: g * (ans != a_min) * (ans != a_max)
@@ -113,17 +154,17 @@ template <> struct Model<TRAJOPT_ENV_CARTPOLE> {
     static constexpr int N = 4, M = 1;
     template <class X> static __device__ __forceinline__ void f(const trajopt_env_t& e, const X (&x)[N], const X (&u)[M], X (&dx)[N]) {
         const double g = e.phys[0], Mc = e.phys[1], Mp = e.phys[2], l = e.phys[3], fr = e.phys[4];
-        const double Mt = Mc + Mp;
+        const double Mt = Mc + Mp, iMt = 1.0 / Mt;   // loop-invariant: hoisted out of the time loop
         X sth, cth;
         sincos_g(x[1], sth, cth);
         const X dq = x[2], dth = x[3];
         const X dth2s = dth * dth * sth;
-        const X num = g * sth + cth * (-(u[0] - fr * dq) - (Mp * l) * dth2s) / Mt;
-        const X den = l * ((4.0 / 3.0) - Mp * cth * cth / Mt);
+        const X num = g * sth + cth * (-(u[0] - fr * dq) - (Mp * l) * dth2s) * iMt;
+        const X den = l * ((4.0 / 3.0) - (Mp * iMt) * cth * cth);
         const X ddth = num / den;
         dx[0] = dq;
         dx[1] = dth;
-        dx[2] = (u[0] + (Mp * l) * (dth2s - ddth * cth)) / Mt;
+        dx[2] = (u[0] + (Mp * l) * (dth2s - ddth * cth)) * iMt;
         dx[3] = ddth;
     }
 };
@@ -151,10 +192,11 @@ template <> struct Model<TRAJOPT_ENV_DOUBLE_CARTPOLE> {
         const X l21 = m12 * i11, l31 = m13 * i11;
         const X a22 = m22 - l21 * m12, a23 = m23 - l21 * m13, a33 = m33 - l31 * m13;
         const X b1 = r1 - l21 * r0, b2 = r2 - l31 * r0;
-        const X l32 = a23 / a22;
+        const X i22 = recip_g(a22);
+        const X l32 = a23 * i22;
         const X c33 = a33 - l32 * a23;
         const X y2 = (b2 - l32 * b1) / c33;
-        const X y1 = (b1 - a23 * y2) / a22;
+        const X y1 = (b1 - a23 * y2) * i22;
         const X y0 = (r0 - m12 * y1 - m13 * y2) * i11;
         dx[0] = x[3]; dx[1] = dth1; dx[2] = dth2; dx[3] = y0; dx[4] = y1; dx[5] = y2;
     }
@@ -171,18 +213,19 @@ template <> struct Model<TRAJOPT_ENV_QUADROTOR> {
         sincos_g(x[5], sps, cps);
         const X p = x[9], q = x[10], r = x[11];
         const X F = (u[0] + u[1] + u[2] + u[3]) * im;
-        const X tth = sth / cth;
+        const X icth = recip_g(cth);
+        const X tth = sth * icth;
         const X sq_cr = sph * q + cph * r;
         dx[0] = x[6]; dx[1] = x[7]; dx[2] = x[8];
         dx[3] = p + tth * sq_cr;
         dx[4] = cph * q - sph * r;
-        dx[5] = sq_cr / cth;
+        dx[5] = sq_cr * icth;
         dx[6] = (cph * sth * cps + sph * sps) * F;
         dx[7] = (cph * sth * sps - sph * cps) * F;
         dx[8] = cph * cth * F - g;
-        dx[9] = (L * (u[1] - u[3]) - (Izz - Iyy) * q * r) / Ixx;
-        dx[10] = (L * (u[2] - u[0]) - (Ixx - Izz) * p * r) / Iyy;
-        dx[11] = (kM * (u[0] - u[1] + u[2] - u[3]) - (Iyy - Ixx) * p * q) / Izz;
+        dx[9] = (L * (u[1] - u[3]) - (Izz - Iyy) * q * r) * (1.0 / Ixx);
+        dx[10] = (L * (u[2] - u[0]) - (Ixx - Izz) * p * r) * (1.0 / Iyy);
+        dx[11] = (kM * (u[0] - u[1] + u[2] - u[3]) - (Iyy - Ixx) * p * q) * (1.0 / Izz);
     }
 };
 
@@ -237,10 +280,15 @@ __device__ __forceinline__ void lqr_dynamics(const trajopt_env_t& e, const X (&x
     }
 }
 
-__device__ __forceinline__ double wrap_angle(double x) {  // ((x + pi) % 2pi) - pi with Python's %
-    const double two_pi = 2.0 * M_PI;
-    double r = fmod(x + M_PI, two_pi);
-    if (r < 0.0) r += two_pi;
+// ((x + pi) % 2pi) - pi with Python's % (result in [-pi, pi)).  floor-based instead of fmod: the library fmod
+// is a loop of frexp/ldexp steps; this form differs from it by ~|x| * 1e-16.
+__device__ __forceinline__ double wrap_angle(double x) {
+    const double two_pi = 6.28318530717958623200e+00;
+    const double y = x + M_PI;
+    const double k = floor(y * 1.59154943091895345554e-01);
+    double r = fma(-k, 2.44929359829470641435e-16, fma(-k, two_pi, y));
+    r = (r < 0.0) ? r + two_pi : r;
+    r = (r >= two_pi) ? r - two_pi : r;
     return r - M_PI;
 }
 

@@ -15,6 +15,12 @@
 
 namespace trajopt {
 
+struct QuadCommit {  // see QuadArgs::sel
+    const int32_t* sel;
+    const double *cand_state, *cand_action, *cand_K, *cand_kff;
+    double *xref, *uref, *K, *kff;
+};
+
 struct QuadArgs {
     trajopt_env_t env;
     const double *xref, *uref, *weighting;
@@ -22,6 +28,12 @@ struct QuadArgs {
     double *A, *B, *c, *Cxx, *cx, *Cuu, *cu, *Cxu;
     size_t NP;
     int T, convention;
+    // Optional fused commit of the previous iteration's line search (driver only; ilqr.py:210-217): when `sel`
+    // is non-NULL and sel[p] >= 0 the reference trajectory is READ from candidate plane sel[p] and written
+    // through to xref/uref (which alias c_xref/c_uref), and the candidate gains are promoted to K/kff.
+    const int32_t* sel;
+    const double *cand_state, *cand_action, *cand_K, *cand_kff;
+    double *c_xref, *c_uref, *c_K, *c_kff;
 };
 
 template <bool MINOR>
@@ -35,26 +47,55 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
     const trajopt_env_t& e = a.env;
     const int n = SYS::n(e), m = SYS::m(e), T = a.T;
     const size_t NP = a.NP;
-    const int nchunk = (n + m + KC - 1) / KC;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t per_chunk = NP * (size_t)(T + 1);
-    if (idx >= per_chunk * nchunk) return;
-    const int chunk = (int)(idx / per_chunk);
-    const size_t r = idx % per_chunk;
-    const int t = (int)(r / NP);
-    const size_t p = r % NP;
-    if (a.active && a.active[p] == 0) return;
+    // grid = (problem blocks, T + 1, tangent chunks): no 64-bit division in the index math
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = (int)blockIdx.y, chunk = (int)blockIdx.z;
+    if (p >= NP) return;
     const size_t En1 = (size_t)n * (T + 1), Em = (size_t)m * T;
+    // a problem that was accepted AND stopped in the previous iteration is inactive now but still has to be
+    // committed, so the activity test comes after the commit
+    const bool live = !(a.active && a.active[p] == 0);
+    if (!live && !(a.sel && chunk == 0 && a.sel[p] >= 0)) return;
 
+    const double* xsrc = a.xref;
+    const double* usrc = a.uref;
+    bool commit = false;
+    if (a.sel) {
+        const int k = a.sel[p];
+        if (k >= 0) {
+            xsrc = a.cand_state + (size_t)k * En1 * NP;
+            usrc = a.cand_action + (size_t)k * Em * NP;
+            commit = (chunk == 0);
+        }
+    }
     double x[N], u[M], ul[M];
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = (i < n) ? a.xref[qi<MINOR>((size_t)n * t + i, En1, p, NP)] : 0.0;
+    for (int i = 0; i < N; ++i) x[i] = (i < n) ? xsrc[qi<MINOR>((size_t)n * t + i, En1, p, NP)] : 0.0;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         // _u = hstack(u, 0): the pad is u_T and, through Python's negative index, also u_last at t = 0
-        u[j] = (j < m && t < T) ? a.uref[qi<MINOR>((size_t)m * t + j, Em, p, NP)] : 0.0;
-        ul[j] = (j < m && t >= 1) ? a.uref[qi<MINOR>((size_t)m * (t - 1) + j, Em, p, NP)] : 0.0;
+        u[j] = (j < m && t < T) ? usrc[qi<MINOR>((size_t)m * t + j, Em, p, NP)] : 0.0;
+        ul[j] = (j < m && t >= 1) ? usrc[qi<MINOR>((size_t)m * (t - 1) + j, Em, p, NP)] : 0.0;
     }
+    if (commit) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i < n) a.c_xref[qi<MINOR>((size_t)n * t + i, En1, p, NP)] = x[i];
+        if (t < T) {
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if (j < m) {
+                    a.c_uref[qi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
+                    a.c_kff[qi<MINOR>((size_t)m * t + j, Em, p, NP)] = a.cand_kff[qi<MINOR>((size_t)m * t + j, Em, p, NP)];
+                }
+            const size_t Enm_ = (size_t)n * m * T;
+#pragma unroll
+            for (int k = 0; k < N * M; ++k)
+                if (k < n * m)
+                    a.c_K[qi<MINOR>((size_t)n * m * t + k, Enm_, p, NP)] = a.cand_K[qi<MINOR>((size_t)n * m * t + k, Enm_, p, NP)];
+        }
+    }
+    if (!live) return;
 
     if (t < T) {  // dynamics Jacobian columns of this chunk
         const int k0 = chunk * KC;
@@ -119,10 +160,9 @@ __global__ __launch_bounds__(64) void riccati_fixup_kernel(QuadArgs a) {
     const trajopt_env_t& e = a.env;
     const int n = SYS::n(e), m = SYS::m(e), T = a.T;
     const size_t NP = a.NP;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= NP * (size_t)(T + 1)) return;
-    const int t = (int)(idx / NP);
-    const size_t p = idx % NP;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = (int)blockIdx.y;
+    if (p >= NP) return;
     if (a.active && a.active[p] == 0) return;
     const size_t En1 = (size_t)n * (T + 1), Em = (size_t)m * T, En = (size_t)n * T;
     const size_t Enn = (size_t)n * n * T, Enm = (size_t)n * m * T;
@@ -195,14 +235,12 @@ struct QuadLaunch {
         constexpr int KC = ChunkOf<SYS>::KC;
         const int n = a.env.dm_state, m = a.env.dm_act;
         const int nchunk = (n + m + KC - 1) / KC;
-        const size_t total = a.NP * (size_t)(a.T + 1) * nchunk;
-        const dim3 grid((unsigned)((total + 63) / 64)), block(64);
+        const dim3 grid((unsigned)((a.NP + 63) / 64), (unsigned)(a.T + 1), (unsigned)nchunk), block(64);
         const bool minor = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
         if (minor) hipLaunchKernelGGL((quadratize_kernel<SYS, KC, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((quadratize_kernel<SYS, KC, false>), grid, block, 0, st, a);
         if (a.convention == 1) {
-            const size_t tot2 = a.NP * (size_t)(a.T + 1);
-            const dim3 grid2((unsigned)((tot2 + 63) / 64));
+            const dim3 grid2((unsigned)((a.NP + 63) / 64), (unsigned)(a.T + 1));
             if (minor) hipLaunchKernelGGL((riccati_fixup_kernel<SYS, true>), grid2, block, 0, st, a);
             else hipLaunchKernelGGL((riccati_fixup_kernel<SYS, false>), grid2, block, 0, st, a);
         }
@@ -211,9 +249,19 @@ struct QuadLaunch {
 
 int launch_quadratize(const trajopt_env_t* env, int T, int64_t NP, int layout, int convention, const double* xref,
                       const double* uref, const double* weighting, const int32_t* active, double* A, double* B,
-                      double* c, double* Cxx, double* cx, double* Cuu, double* cu, double* Cxu, hipStream_t st) {
+                      double* c, double* Cxx, double* cx, double* Cuu, double* cu, double* Cxu, hipStream_t st,
+                      const QuadCommit* cm) {
     QuadLaunch L;
     L.a.env = *env;
+    L.a.sel = nullptr;
+    L.a.cand_state = L.a.cand_action = L.a.cand_K = L.a.cand_kff = nullptr;
+    L.a.c_xref = L.a.c_uref = L.a.c_K = L.a.c_kff = nullptr;
+    if (cm) {
+        if (layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
+        L.a.sel = cm->sel; L.a.cand_state = cm->cand_state; L.a.cand_action = cm->cand_action;
+        L.a.cand_K = cm->cand_K; L.a.cand_kff = cm->cand_kff;
+        L.a.c_xref = cm->xref; L.a.c_uref = cm->uref; L.a.c_K = cm->K; L.a.c_kff = cm->kff;
+    }
     L.a.xref = xref; L.a.uref = uref; L.a.weighting = weighting; L.a.active = active;
     L.a.A = A; L.a.B = B; L.a.c = c; L.a.Cxx = Cxx; L.a.cx = cx; L.a.Cuu = Cuu; L.a.cu = cu; L.a.Cxu = Cxu;
     L.a.NP = (size_t)NP; L.a.T = T; L.a.convention = convention;
@@ -238,5 +286,5 @@ extern "C" int trajopt_quadratize_batched(const trajopt_env_t* env, int nb_steps
     if (convention != 0 && convention != 1) return TRAJOPT_ERR_BAD_ARG;
     if (convention == 1 && !c) return TRAJOPT_ERR_BAD_ARG;
     return launch_quadratize(env, nb_steps, nb_problems, layout, convention, xref, uref, weighting, active, A, B, c, Cxx,
-                             cx, Cuu, cu, Cxu, as_stream(stream));
+                             cx, Cuu, cu, Cxu, as_stream(stream), nullptr);
 }
