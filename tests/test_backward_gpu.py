@@ -47,6 +47,58 @@ def test_ilqr_backward_matches_oracle(oracle, n, m, T, N, layout, reg):
             assert_close(res[k][p], r, "%s[p=%d]" % (k, p))
 
 
+@pytest.fixture
+def force_kernel():
+    """Route the batched entry to one kernel family: 1 workgroup-per-problem, 2 MFMA wave-per-problem,
+    3 lane-per-problem (0 = the library's own choice)."""
+    from trajopt_amd._lib import lib
+    yield lambda which: lib().trajopt_debug_force_kernel(int(which))
+    lib().trajopt_debug_force_kernel(0)
+
+
+@pytest.mark.parametrize("kernel,n,m,T,N,layout", [
+    (1, 4, 1, 40, 9, 1), (1, 6, 1, 30, 5, 0), (1, 12, 4, 20, 3, 1), (1, 12, 4, 20, 3, 0),      # workgroup = problem
+    (2, 4, 1, 40, 9, 1), (2, 4, 1, 40, 9, 0), (2, 6, 1, 50, 7, 0), (2, 6, 1, 50, 7, 1),        # wave = problem (MFMA)
+    (2, 12, 4, 40, 6, 0), (2, 12, 4, 40, 6, 1), (2, 8, 2, 25, 4, 0), (2, 13, 3, 12, 3, 0), (2, 15, 1, 12, 3, 1),
+    (2, 3, 2, 12, 3, 0), (2, 9, 4, 12, 3, 0), (2, 2, 1, 12, 3, 1),
+    (3, 6, 1, 50, 70, 1), (3, 4, 2, 30, 66, 1), (3, 2, 1, 30, 5, 1),                            # lane = problem
+])
+@pytest.mark.parametrize("reg", [1, 2])
+def test_every_kernel_family_matches_oracle(oracle, force_kernel, kernel, n, m, T, N, layout, reg):
+    from trajopt_amd import synthetic as S
+    force_kernel(kernel)
+    stack = S.backward_inputs(n, m, T, N, seed=4000 + 10 * n + m)
+    uref = np.random.default_rng(n).standard_normal((N, m, T))
+    res = _run_gpu(stack, 0.8, reg, n, m, T, N, layout, uref=uref)
+    for p in range(N):
+        q = S.problem(stack, p)
+        ref, failed = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], 0.8, reg, n,
+                                           m, T)
+        assert not failed and res["diverge"][p] == -1
+        for k, r in zip(OUT, ref[:10]):
+            assert_close(res[k][p], r, "%s[p=%d]" % (k, p))
+        g = np.mean(np.max(np.abs(ref[9]) / (np.abs(uref[p]) + 1.0), axis=1))
+        assert res["g_norm"][p] == pytest.approx(g, rel=1e-9)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_asymmetric_cost_hessians_are_taken_as_given(oracle, force_kernel, kernel):
+    """util.cpp uses Cxx as passed (no symmetry assumed); only V is symmetrised (:161)."""
+    from trajopt_amd import synthetic as S
+    n, m, T, N = 6, 2, 10, 3
+    force_kernel(kernel)
+    stack = S.backward_inputs(n, m, T, N, seed=99)
+    Cxx = np.array(stack["Cxx"])
+    Cxx[:, 0, 1, :] += 0.05          # asymmetric, terminal slice included
+    stack = dict(stack, Cxx=Cxx)
+    res = _run_gpu(stack, 1.0, 1, n, m, T, N, 0)
+    for p in range(N):
+        q = S.problem(stack, p)
+        ref, _ = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], 1.0, 1, n, m, T)
+        for k, r in zip(OUT, ref[:10]):
+            assert_close(res[k][p], r, "%s[p=%d]" % (k, p))
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("n,m,T,N", [(4, 1, 500, 64), (6, 1, 500, 64)])
 def test_gains_only_long_horizon(oracle, n, m, T, N, layout):

@@ -16,7 +16,7 @@ void set_hip_error(hipError_t e, const char* where) {
 
 extern int g_tpp_dbg_same_step;
 extern int g_tpp_lpw;
-static int g_force_kernel = 0;  // 0 auto, 1 always the workgroup-per-problem kernel (tests)
+static int g_force_kernel = 0;  // tests / benches: 0 auto, 1 workgroup-per-problem, 2 MFMA wave-per-problem, 3 lane-per-problem
 
 template <bool TO_MINOR>
 __global__ void convert_layout_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t E, size_t NP) {
@@ -96,8 +96,20 @@ int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg,
     if (retry && !sched) return TRAJOPT_ERR_BAD_ARG;
     trajopt_lambda_schedule_t s = sched ? *sched : trajopt_lambda_schedule_t{1e-6, 1e6, 1.6};
     hipStream_t st = as_stream(stream);
-    // NP == 1: the two layouts are the same memory
-    if ((layout == TRAJOPT_LAYOUT_PROBLEM_MINOR || NP == 1) && g_force_kernel == 0 && tpp_offsets_fit(n, NP)) {
+    // Kernel choice:  lane = problem (dx <= 4, struct-of-arrays layout; NP == 1: the two layouts are the same
+    // memory)  ->  wave = problem on the fp64 matrix cores (dx + du <= 16, du <= 4)  ->  workgroup = problem.
+    const bool tpp_ok = (layout == TRAJOPT_LAYOUT_PROBLEM_MINOR || NP == 1) && tpp_offsets_fit(n, NP);
+    if (tpp_ok && (g_force_kernel == 3 || (g_force_kernel == 0 && n <= 4))) {
+        bool handled = false;
+        const int rc = launch_backward_tpp(*io, reg, n, m, T, NP, retry, s, st, &handled);
+        if (rc != TRAJOPT_OK || handled) return rc;
+    }
+    if (g_force_kernel == 0 || g_force_kernel == 2) {
+        bool handled = false;
+        const int rc = launch_backward_mfma16(*io, reg, n, m, T, NP, layout, retry, s, st, &handled);
+        if (rc != TRAJOPT_OK || handled) return rc;
+    }
+    if (tpp_ok && g_force_kernel == 0) {
         bool handled = false;
         const int rc = launch_backward_tpp(*io, reg, n, m, T, NP, retry, s, st, &handled);
         if (rc != TRAJOPT_OK || handled) return rc;
