@@ -96,10 +96,11 @@ int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg,
     if (retry && !sched) return TRAJOPT_ERR_BAD_ARG;
     trajopt_lambda_schedule_t s = sched ? *sched : trajopt_lambda_schedule_t{1e-6, 1e6, 1.6};
     hipStream_t st = as_stream(stream);
-    // Kernel choice:  lane = problem (dx <= 4, struct-of-arrays layout; NP == 1: the two layouts are the same
-    // memory)  ->  wave = problem on the fp64 matrix cores (dx + du <= 16, du <= 4)  ->  workgroup = problem.
+    // Kernel choice:  lane = problem for the struct-of-arrays layout and dx <= 6 (NP == 1: the two layouts are the
+    // same memory)  ->  wave = problem on the fp64 matrix cores (dx + du <= 16, du <= 4; best with PROBLEM_MAJOR,
+    // whose per-step slices are contiguous)  ->  workgroup = problem.
     const bool tpp_ok = (layout == TRAJOPT_LAYOUT_PROBLEM_MINOR || NP == 1) && tpp_offsets_fit(n, NP);
-    if (tpp_ok && (g_force_kernel == 3 || (g_force_kernel == 0 && n <= 4))) {
+    if (tpp_ok && (g_force_kernel == 3 || g_force_kernel == 0)) {
         bool handled = false;
         const int rc = launch_backward_tpp(*io, reg, n, m, T, NP, retry, s, st, &handled);
         if (rc != TRAJOPT_OK || handled) return rc;
@@ -107,11 +108,6 @@ int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg,
     if (g_force_kernel == 0 || g_force_kernel == 2) {
         bool handled = false;
         const int rc = launch_backward_mfma16(*io, reg, n, m, T, NP, layout, retry, s, st, &handled);
-        if (rc != TRAJOPT_OK || handled) return rc;
-    }
-    if (tpp_ok && g_force_kernel == 0) {
-        bool handled = false;
-        const int rc = launch_backward_tpp(*io, reg, n, m, T, NP, retry, s, st, &handled);
         if (rc != TRAJOPT_OK || handled) return rc;
     }
     return launch_backward_wg(*io, reg, n, m, T, NP, layout, retry, s, st);

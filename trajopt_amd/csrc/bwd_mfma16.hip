@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
 
     double lam = io.lmbda[p];
     double dlam = (a.retry && io.dlmbda) ? io.dlmbda[p] : 1.0;
-    int div = -1;
+    int div = -1, retries = 0;
     double dV0 = 0.0, dV1 = 0.0, gmax = -INFINITY;
 
     for (;;) {
@@ -306,7 +306,9 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
         if (div < 0 || !a.retry) break;
         dlam = fmax(dlam * a.sched.mult_lmbda, a.sched.mult_lmbda);  // ilqr.py:166-169
         lam = fmax(lam * dlam, a.sched.min_lmbda);
-        if (lam > a.sched.max_lmbda) break;
+        // exit every wave reaches: also when lam can no longer grow (max_lmbda = inf, NaN inputs) - the
+        // reference's `while not backpass_done` would spin forever there (ilqr.py:162-173)
+        if (!(lam <= a.sched.max_lmbda) || !(lam < 1e300) || ++retries >= kMaxLambdaRetries) break;
         __syncthreads();
     }
 

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
     const Lane off{lane * 8u, NP};  // host guarantees N*N*NP*8 + 512 < 2^32
     double lam = a.io.lmbda[p];
     double dlam = (a.retry && a.io.dlmbda) ? a.io.dlmbda[p] : 1.0;
-    int div = -1;
+    int div = -1, retries = 0;
     double dV0 = 0.0, dV1 = 0.0;
     double gmax[M];
 
@@ -352,7 +352,9 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
         // ilqr.py:166-169
         dlam = fmax(dlam * a.sched.mult_lmbda, a.sched.mult_lmbda);
         lam = fmax(lam * dlam, a.sched.min_lmbda);
-        if (lam > a.sched.max_lmbda) break;
+        // exit every wave reaches: also when lam can no longer grow (max_lmbda = inf, NaN inputs) - the
+        // reference's `while not backpass_done` would spin forever there (ilqr.py:162-173)
+        if (!(lam <= a.sched.max_lmbda) || !(lam < 1e300) || ++retries >= kMaxLambdaRetries) break;
     }
     a.io.diverge[p] = div;
     a.io.dV[p] = dV0;

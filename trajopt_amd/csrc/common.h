@@ -26,6 +26,7 @@ __host__ __device__ inline size_t elem_off(size_t e, size_t p, size_t NP, size_t
 }
 
 constexpr double kEps = 2.220446049250313e-16;
+constexpr int kMaxLambdaRetries = 128;  // lambda grows super-exponentially: 1e-6 -> 1e300 takes < 70 retries
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
