@@ -169,7 +169,8 @@ int trajopt_quadratize_batched(const trajopt_env_t* env, int nb_steps, int64_t n
 
 /* ------------------------------------------------------------------------------------------------
  * A6.  Batched iLQR driver: everything iLQR.run keeps per problem (ilqr.py:136-237), resident on the
- * device, PROBLEM_MINOR layout.  The caller (PyTorch on the Python side) owns every buffer.
+ * device, PROBLEM_MINOR layout except for the gains group (see gains_layout).  The caller (PyTorch on the
+ * Python side) owns every buffer.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct trajopt_ilqr_options {
     trajopt_lambda_schedule_t sched;
@@ -184,7 +185,11 @@ typedef struct trajopt_ilqr_options {
 } trajopt_ilqr_options_t;
 
 typedef struct trajopt_ilqr_workspace {
-    int32_t nb_steps; int32_t pad_;
+    int32_t nb_steps;
+    /* Layout of the "gains group": A, B, Cxx, cx, Cuu, cu, Cxu, K, kff, cand_K, cand_kff and the vfunc/qfunc
+     * arrays.  Everything else (x0, xref, uref, candidates, per-problem scalars) is always PROBLEM_MINOR.
+     * PROBLEM_MINOR suits the lane-per-problem backward kernel (dx <= 6), PROBLEM_MAJOR the matrix-core one. */
+    int32_t gains_layout;
     int64_t nb_problems;
     /* problem data */
     const double* x0;         /* (n,)            */
@@ -201,7 +206,7 @@ typedef struct trajopt_ilqr_workspace {
     int32_t* trace_len;   /* entries written to trace                                                 */
     double* trace;        /* [trace_cap][nb_problems] accepted returns (ilqr.py:149,219)             */
     int32_t trace_cap; int32_t pad2_;
-    /* scratch, all PROBLEM_MINOR */
+    /* scratch */
     double* A; double* B; double* Cxx; double* cx; double* Cuu; double* cu; double* Cxu;   /* quadratisation */
     double* cand_K; double* cand_kff;    /* backward-pass candidate gains                             */
     double* cand_V; double* cand_v; double* cand_Qxx; double* cand_Qux; double* cand_Quu; double* cand_qx;

@@ -164,13 +164,14 @@ def test_quadratize_matches_oracle(oracle, name, layout, convention):
             assert np.abs(h[k][p] - ref[k]).max() <= 1e-10 * den, "%s %s[%d]" % (name, k, p)
 
 
-def _solve_pair(oracle, name, N, T, iters, seed=1337, scale=1e-2, **kw):
+def _solve_pair(oracle, name, N, T, iters, seed=1337, scale=1e-2, gains_layout=None, **kw):
     from trajopt_amd.ilqr import BatchedILQR
     pe, oe = _pair(name, **kw)
     rng = np.random.Generator(np.random.PCG64(seed))
     x0 = np.asarray(pe.x0)[None] + scale * rng.standard_normal((N, pe.dm_state))
     kff0 = 1e-4 * rng.standard_normal((N, pe.dm_act, T))
-    s = BatchedILQR(pe, T, x0, kff_init=kff0, action_penalty=None, keep_value=True, apply_env_kwargs=False)
+    s = BatchedILQR(pe, T, x0, kff_init=kff0, action_penalty=None, keep_value=True, apply_env_kwargs=False,
+                    gains_layout=gains_layout)
     traces = s.run(nb_iter=iters)
     refs = [oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=iters) for p in range(N)]
     return s, traces, refs
@@ -180,8 +181,11 @@ def _solve_pair(oracle, name, N, T, iters, seed=1337, scale=1e-2, **kw):
     ("pendulum", 100, 5, dict(dt=0.05, uw=[1e-5])),           # config C1's shape (examples/ilqr/mpc/pendulum.py)
     ("cartpole", 60, 4, dict(dt=0.02, uw=[1e-5])),
     ("double_cartpole", 50, 3, dict(dt=0.01, uw=[1e-5])),
-    ("quadrotor", 40, 3, dict(dt=0.02)),
+    ("quadrotor", 40, 3, dict(dt=0.02)),                      # gains group defaults to PROBLEM_MAJOR (dx > 6)
     ("lqr", 60, 5, dict()),
+    ("cartpole", 40, 4, dict(dt=0.02, uw=[1e-5], gains_layout=0)),          # forced PROBLEM_MAJOR gains group
+    ("double_cartpole", 30, 3, dict(dt=0.01, uw=[1e-5], gains_layout=0)),
+    ("quadrotor", 30, 2, dict(dt=0.02, gains_layout=1)),                    # forced PROBLEM_MINOR
 ])
 def test_batched_driver_matches_oracle_driver(oracle, name, T, iters, kw):
     """ilqr.py:136-237 per problem: same accepted iterates, lambda schedule, traces and stop reasons."""

@@ -58,7 +58,7 @@ class ILQROptions(C.Structure):
 
 
 class ILQRWorkspace(C.Structure):
-    _fields_ = ([("nb_steps", C.c_int32), ("pad_", C.c_int32), ("nb_problems", C.c_int64)] +
+    _fields_ = ([("nb_steps", C.c_int32), ("gains_layout", C.c_int32), ("nb_problems", C.c_int64)] +
                 [(k, _dp) for k in
                  ("x0", "weighting", "xref", "uref", "K", "kff", "V", "v", "Qxx", "Qux", "Quu", "qx", "qu",
                   "last_return", "lmbda", "dlmbda", "alpha", "status", "iters", "trace_len", "trace")] +

@@ -6,7 +6,7 @@
 //        -> gradient-norm stop (ilqr.py:176-180) -> rollout of every alpha at once (ilqr.py:187-191)
 //        -> first-accept selection + lambda update + stopping rules (ilqr.py:193-231) -> commit.
 // Problems that have stopped keep their slot and are masked out through `active`.
-// Everything is PROBLEM_MINOR.
+// Everything is PROBLEM_MINOR except the gains group (ws->gains_layout, see include/trajopt_amd.h).
 #include "sys.h"
 
 namespace trajopt {
@@ -14,7 +14,7 @@ namespace trajopt {
 int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, const double* x0, const double* K,
                    const double* kff, const double* xref, const double* uref, const double* weighting,
                    const double* alphas_host, int nb_alphas, const int32_t* active, double* state, double* action,
-                   double* cost, double* ret, int32_t* finite, hipStream_t st);
+                   double* cost, double* ret, int32_t* finite, hipStream_t st, int k_layout);
 struct QuadCommit {  // fused commit of the previous line search inside the quadratisation (quadratize.hip)
     const int32_t* sel;
     const double *cand_state, *cand_action, *cand_K, *cand_kff;
@@ -23,7 +23,7 @@ struct QuadCommit {  // fused commit of the previous line search inside the quad
 int launch_quadratize(const trajopt_env_t* env, int T, int64_t NP, int layout, int convention, const double* xref,
                       const double* uref, const double* weighting, const int32_t* active, double* A, double* B,
                       double* c, double* Cxx, double* cx, double* Cuu, double* cu, double* Cxu, hipStream_t st,
-                      const QuadCommit* cm);
+                      const QuadCommit* cm, int out_layout);
 
 struct DrvArgs {
     trajopt_ilqr_options_t opt;
@@ -132,6 +132,12 @@ __global__ void select_kernel(DrvArgs a) {
 
 // Copy the accepted candidate into the reference slots (ilqr.py:210-217 / :142-143).  Thread per
 // (problem, step); `with_ctl` also promotes the candidate gains (and value functions if kept).
+template <bool GMINOR>
+__device__ __forceinline__ size_t gidx(size_t eps, size_t slices, int t, size_t e, size_t p, size_t NP) {
+    return GMINOR ? (eps * (size_t)t + e) * NP + p : p * eps * slices + eps * (size_t)t + e;
+}
+
+template <bool GMINOR>
 __global__ void commit_kernel(DrvArgs a, int with_ctl) {
     const size_t NP = (size_t)a.ws.nb_problems;
     const int T = a.ws.nb_steps, n = a.n, m = a.m;
@@ -148,21 +154,50 @@ __global__ void commit_kernel(DrvArgs a, int with_ctl) {
         for (int j = 0; j < m; ++j) a.ws.uref[((size_t)m * t + j) * NP + p] = ac[((size_t)m * t + j) * NP + p];
     }
     if (!with_ctl) return;
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
+#define TJ_COPY(dst, src, eps, slices, cnt) \
+    for (size_t k = 0; k < (cnt); ++k) { const size_t o = gidx<GMINOR>(eps, slices, t, k, p, NP); a.ws.dst[o] = a.ws.src[o]; }
     if (t < T) {
-        for (int k = 0; k < n * m; ++k) a.ws.K[((size_t)n * m * t + k) * NP + p] = a.ws.cand_K[((size_t)n * m * t + k) * NP + p];
-        for (int j = 0; j < m; ++j) a.ws.kff[((size_t)m * t + j) * NP + p] = a.ws.cand_kff[((size_t)m * t + j) * NP + p];
+        TJ_COPY(K, cand_K, nm, T, nm)
+        TJ_COPY(kff, cand_kff, m, T, (size_t)m)
     }
     if (a.opt.keep_value) {
-        for (int k = 0; k < n * n; ++k) a.ws.V[((size_t)n * n * t + k) * NP + p] = a.ws.cand_V[((size_t)n * n * t + k) * NP + p];
-        for (int i = 0; i < n; ++i) a.ws.v[((size_t)n * t + i) * NP + p] = a.ws.cand_v[((size_t)n * t + i) * NP + p];
+        TJ_COPY(V, cand_V, nn, T + 1, nn)
+        TJ_COPY(v, cand_v, n, T + 1, (size_t)n)
         if (t < T) {
-            for (int k = 0; k < n * n; ++k) a.ws.Qxx[((size_t)n * n * t + k) * NP + p] = a.ws.cand_Qxx[((size_t)n * n * t + k) * NP + p];
-            for (int k = 0; k < n * m; ++k) a.ws.Qux[((size_t)n * m * t + k) * NP + p] = a.ws.cand_Qux[((size_t)n * m * t + k) * NP + p];
-            for (int k = 0; k < m * m; ++k) a.ws.Quu[((size_t)m * m * t + k) * NP + p] = a.ws.cand_Quu[((size_t)m * m * t + k) * NP + p];
-            for (int i = 0; i < n; ++i) a.ws.qx[((size_t)n * t + i) * NP + p] = a.ws.cand_qx[((size_t)n * t + i) * NP + p];
-            for (int j = 0; j < m; ++j) a.ws.qu[((size_t)m * t + j) * NP + p] = a.ws.cand_qu[((size_t)m * t + j) * NP + p];
+            TJ_COPY(Qxx, cand_Qxx, nn, T, nn)
+            TJ_COPY(Qux, cand_Qux, nm, T, nm)
+            TJ_COPY(Quu, cand_Quu, mm, T, mm)
+            TJ_COPY(qx, cand_qx, n, T, (size_t)n)
+            TJ_COPY(qu, cand_qu, m, T, (size_t)m)
         }
     }
+#undef TJ_COPY
+}
+
+// ilqr.py:176 for the PROBLEM_MAJOR gains group (the backward kernels only fuse it when kff and uref share a
+// layout): g_norm[p] = mean_j max_t |kff_jt| / (|uref_jt| + 1).  One wave per problem.
+__global__ __launch_bounds__(64) void gnorm_major_kernel(DrvArgs a) {
+    const size_t NP = (size_t)a.ws.nb_problems, p = blockIdx.x;
+    if (!a.ws.active[p]) return;
+    const int T = a.ws.nb_steps, m = a.m, lane = threadIdx.x;
+    double acc = 0.0;
+    for (int j = 0; j < m; ++j) {
+        double mx = -INFINITY;
+        bool nan_seen = false;
+        for (int t = lane; t < T; t += 64) {
+            const double q = fabs(a.ws.cand_kff[p * (size_t)m * T + (size_t)m * t + j]) /
+                             (fabs(a.ws.uref[((size_t)m * t + j) * NP + p]) + 1.0);
+            nan_seen = nan_seen || (q != q);
+            mx = fmax(mx, q);
+        }
+        for (int o = 32; o >= 1; o >>= 1) {
+            mx = fmax(mx, __shfl_xor(mx, o, 64));
+            nan_seen = nan_seen || __shfl_xor((int)nan_seen, o, 64);
+        }
+        acc += nan_seen ? NAN : mx;
+    }
+    if (lane == 0) a.ws.g_norm[p] = acc / m;
 }
 
 // ---- optional per-phase timing of trajopt_ilqr_iterate (bench.py's roofline leg) ------------------------
@@ -197,6 +232,8 @@ static int check_ws(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
             if (!q) return TRAJOPT_ERR_BAD_ARG;
     }
     if (ws->trace_cap < 1) return TRAJOPT_ERR_BAD_ARG;
+    if (ws->gains_layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && ws->gains_layout != TRAJOPT_LAYOUT_PROBLEM_MINOR)
+        return TRAJOPT_ERR_BAD_ARG;
     return TRAJOPT_OK;
 }
 
@@ -215,12 +252,12 @@ int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_optio
     const int T = ws->nb_steps;
     rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->K, ws->kff, ws->xref, ws->uref,
                         ws->weighting, opt->alphas, opt->nb_alphas, nullptr, ws->cand_state, ws->cand_action, nullptr,
-                        ws->cand_ret, ws->cand_finite, st);
+                        ws->cand_ret, ws->cand_finite, st, ws->gains_layout);
     if (rc != TRAJOPT_OK) return rc;
     DrvArgs a{*opt, *ws, env->dm_state, env->dm_act};
     const unsigned g1 = (unsigned)((NP + 255) / 256);
     hipLaunchKernelGGL(init_select_kernel, dim3(g1), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(commit_kernel, dim3(g1, (unsigned)(T + 1)), dim3(256), 0, st, a, 0);
+    hipLaunchKernelGGL(commit_kernel<true>, dim3(g1, (unsigned)(T + 1)), dim3(256), 0, st, a, 0);
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
 }
@@ -243,7 +280,10 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         io.V = ws->cand_V; io.v = ws->cand_v;
     }
     io.dV = ws->dV; io.K = ws->cand_K; io.kff = ws->cand_kff; io.diverge = ws->diverge;
-    io.uref = ws->uref; io.g_norm = ws->g_norm; io.active = ws->active;
+    const int GL = ws->gains_layout;
+    const bool gminor = GL == TRAJOPT_LAYOUT_PROBLEM_MINOR;
+    io.g_norm = ws->g_norm; io.active = ws->active;
+    io.uref = gminor ? ws->uref : nullptr;  // fused gradient norm needs kff and uref in one layout
     const bool fuse_commit = !opt->keep_value;
     const QuadCommit cm{ws->sel, ws->cand_state, ws->cand_action, ws->cand_K, ws->cand_kff,
                         ws->xref, ws->uref, ws->K, ws->kff};
@@ -257,22 +297,25 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         // of the call, and the keep_value mode, use the stand-alone commit kernel.
         rc = launch_quadratize(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 0, ws->xref, ws->uref, ws->weighting,
                                ws->active, ws->A, ws->B, nullptr, ws->Cxx, ws->cx, ws->Cuu, ws->cu, ws->Cxu, st,
-                               (fuse_commit && it > 0) ? &cm : nullptr);
+                               (fuse_commit && it > 0) ? &cm : nullptr, GL);
         if (rc != TRAJOPT_OK) return rc;
         prof_mark(st, slot, 2);
-        rc = trajopt_ilqr_backward_pass_batched(&io, opt->reg, n, m, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 1,
-                                                &opt->sched, st);
+        rc = trajopt_ilqr_backward_pass_batched(&io, opt->reg, n, m, T, NP, GL, 1, &opt->sched, st);
         if (rc != TRAJOPT_OK) return rc;
+        if (!gminor) hipLaunchKernelGGL(gnorm_major_kernel, dim3((unsigned)NP), dim3(64), 0, st, a);
         prof_mark(st, slot, 3);
         hipLaunchKernelGGL(post_backward_kernel, dim3(g1), dim3(256), 0, st, a);
         prof_mark(st, slot, 4);
         rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
                             ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
-                            ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st);
+                            ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL);
         if (rc != TRAJOPT_OK) return rc;
         prof_mark(st, slot, 5);
         hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a);
-        if (!fuse_commit || it == nb_iter - 1) hipLaunchKernelGGL(commit_kernel, g2, dim3(256), 0, st, a, 1);
+        if (!fuse_commit || it == nb_iter - 1) {
+            if (gminor) hipLaunchKernelGGL(commit_kernel<true>, g2, dim3(256), 0, st, a, 1);
+            else hipLaunchKernelGGL(commit_kernel<false>, g2, dim3(256), 0, st, a, 1);
+        }
         prof_mark(st, slot, 6);
     }
     TRAJOPT_HIP_CHECK(hipGetLastError());

@@ -41,7 +41,8 @@ __device__ __forceinline__ size_t qi(size_t e_total, size_t E_total, size_t p, s
     return MINOR ? e_total * NP + p : p * E_total + e_total;
 }
 
-template <class SYS, int KC, bool MINOR>
+// MINOR: layout of xref / uref (and of the candidate planes);  OMINOR: layout of A, B, C.., and of K / kff.
+template <class SYS, int KC, bool MINOR, bool OMINOR>
 __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
     constexpr int N = SYS::N, M = SYS::M;
     const trajopt_env_t& e = a.env;
@@ -86,13 +87,13 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
             for (int j = 0; j < M; ++j)
                 if (j < m) {
                     a.c_uref[qi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
-                    a.c_kff[qi<MINOR>((size_t)m * t + j, Em, p, NP)] = a.cand_kff[qi<MINOR>((size_t)m * t + j, Em, p, NP)];
+                    a.c_kff[qi<OMINOR>((size_t)m * t + j, Em, p, NP)] = a.cand_kff[qi<OMINOR>((size_t)m * t + j, Em, p, NP)];
                 }
             const size_t Enm_ = (size_t)n * m * T;
 #pragma unroll
             for (int k = 0; k < N * M; ++k)
                 if (k < n * m)
-                    a.c_K[qi<MINOR>((size_t)n * m * t + k, Enm_, p, NP)] = a.cand_K[qi<MINOR>((size_t)n * m * t + k, Enm_, p, NP)];
+                    a.c_K[qi<OMINOR>((size_t)n * m * t + k, Enm_, p, NP)] = a.cand_K[qi<OMINOR>((size_t)n * m * t + k, Enm_, p, NP)];
         }
     }
     if (!live) return;
@@ -108,11 +109,11 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
             if (col < n) {
 #pragma unroll
                 for (int i = 0; i < N; ++i)
-                    if (i < n) a.A[qi<MINOR>((size_t)n * n * t + i + (size_t)n * col, Enn, p, NP)] = J[i][k];
+                    if (i < n) a.A[qi<OMINOR>((size_t)n * n * t + i + (size_t)n * col, Enn, p, NP)] = J[i][k];
             } else if (col < n + m) {
 #pragma unroll
                 for (int i = 0; i < N; ++i)
-                    if (i < n) a.B[qi<MINOR>((size_t)n * m * t + i + (size_t)n * (col - n), Enm, p, NP)] = J[i][k];
+                    if (i < n) a.B[qi<OMINOR>((size_t)n * m * t + i + (size_t)n * (col - n), Enm, p, NP)] = J[i][k];
             }
         }
     }
@@ -130,23 +131,23 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
                     h = sc * 2.0 * w * e.gw[i];
                     g = sc * 2.0 * w * e.gw[i] * (y - e.goal[i]);
                 }
-                a.cx[qi<MINOR>((size_t)n * t + i, En1, p, NP)] = g;
+                a.cx[qi<OMINOR>((size_t)n * t + i, En1, p, NP)] = g;
 #pragma unroll
                 for (int j = 0; j < N; ++j)
-                    if (j < n) a.Cxx[qi<MINOR>((size_t)n * n * t + j + (size_t)n * i, Enn1, p, NP)] = (i == j) ? h : 0.0;
+                    if (j < n) a.Cxx[qi<OMINOR>((size_t)n * n * t + j + (size_t)n * i, Enn1, p, NP)] = (i == j) ? h : 0.0;
 #pragma unroll
                 for (int j = 0; j < M; ++j)
-                    if (j < m) a.Cxu[qi<MINOR>((size_t)n * m * t + i + (size_t)n * j, Enm1, p, NP)] = 0.0;
+                    if (j < m) a.Cxu[qi<OMINOR>((size_t)n * m * t + i + (size_t)n * j, Enm1, p, NP)] = 0.0;
             }
 #pragma unroll
         for (int j = 0; j < M; ++j)
             if (j < m) {
                 const double d = e.slew_rate ? (u[j] - ul[j]) : u[j];
-                a.cu[qi<MINOR>((size_t)m * t + j, Em1, p, NP)] = sc * 2.0 * e.uw[j] * d;
+                a.cu[qi<OMINOR>((size_t)m * t + j, Em1, p, NP)] = sc * 2.0 * e.uw[j] * d;
 #pragma unroll
                 for (int k = 0; k < M; ++k)
                     if (k < m)
-                        a.Cuu[qi<MINOR>((size_t)m * m * t + k + (size_t)m * j, Emm1, p, NP)] =
+                        a.Cuu[qi<OMINOR>((size_t)m * m * t + k + (size_t)m * j, Emm1, p, NP)] =
                             (k == j) ? sc * 2.0 * e.uw[j] : 0.0;
             }
     }
@@ -226,9 +227,14 @@ template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_CARTPOLE>> { static constexpr int
 template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_DOUBLE_CARTPOLE>> { static constexpr int KC = 4; };
 template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_QUADROTOR>> { static constexpr int KC = 4; };
 
+// the Riccati fix-up kernel reads A, B, C.. with the input layout flag: mixed layouts are an iLQR-driver feature
+static inline bool a_convention_needs_same_layout(int convention, int layout, int out_layout) {
+    return convention == 1 && layout != out_layout;
+}
+
 struct QuadLaunch {
     QuadArgs a;
-    int layout;
+    int layout, out_layout;
     hipStream_t st;
     template <class SYS>
     void operator()() {
@@ -236,9 +242,11 @@ struct QuadLaunch {
         const int n = a.env.dm_state, m = a.env.dm_act;
         const int nchunk = (n + m + KC - 1) / KC;
         const dim3 grid((unsigned)((a.NP + 63) / 64), (unsigned)(a.T + 1), (unsigned)nchunk), block(64);
-        const bool minor = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
-        if (minor) hipLaunchKernelGGL((quadratize_kernel<SYS, KC, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((quadratize_kernel<SYS, KC, false>), grid, block, 0, st, a);
+        const bool minor = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR, ominor = out_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
+        if (minor && ominor) hipLaunchKernelGGL((quadratize_kernel<SYS, KC, true, true>), grid, block, 0, st, a);
+        else if (minor) hipLaunchKernelGGL((quadratize_kernel<SYS, KC, true, false>), grid, block, 0, st, a);
+        else if (ominor) hipLaunchKernelGGL((quadratize_kernel<SYS, KC, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((quadratize_kernel<SYS, KC, false, false>), grid, block, 0, st, a);
         if (a.convention == 1) {
             const dim3 grid2((unsigned)((a.NP + 63) / 64), (unsigned)(a.T + 1));
             if (minor) hipLaunchKernelGGL((riccati_fixup_kernel<SYS, true>), grid2, block, 0, st, a);
@@ -250,7 +258,7 @@ struct QuadLaunch {
 int launch_quadratize(const trajopt_env_t* env, int T, int64_t NP, int layout, int convention, const double* xref,
                       const double* uref, const double* weighting, const int32_t* active, double* A, double* B,
                       double* c, double* Cxx, double* cx, double* Cuu, double* cu, double* Cxu, hipStream_t st,
-                      const QuadCommit* cm) {
+                      const QuadCommit* cm, int out_layout) {
     QuadLaunch L;
     L.a.env = *env;
     L.a.sel = nullptr;
@@ -265,7 +273,8 @@ int launch_quadratize(const trajopt_env_t* env, int T, int64_t NP, int layout, i
     L.a.xref = xref; L.a.uref = uref; L.a.weighting = weighting; L.a.active = active;
     L.a.A = A; L.a.B = B; L.a.c = c; L.a.Cxx = Cxx; L.a.cx = cx; L.a.Cuu = Cuu; L.a.cu = cu; L.a.Cxu = Cxu;
     L.a.NP = (size_t)NP; L.a.T = T; L.a.convention = convention;
-    L.layout = layout; L.st = st;
+    L.layout = layout; L.out_layout = out_layout; L.st = st;
+    if (a_convention_needs_same_layout(convention, layout, out_layout)) return TRAJOPT_ERR_BAD_ARG;
     if (!dispatch_model(*env, L)) return TRAJOPT_ERR_UNSUPPORTED;
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
@@ -286,5 +295,5 @@ extern "C" int trajopt_quadratize_batched(const trajopt_env_t* env, int nb_steps
     if (convention != 0 && convention != 1) return TRAJOPT_ERR_BAD_ARG;
     if (convention == 1 && !c) return TRAJOPT_ERR_BAD_ARG;
     return launch_quadratize(env, nb_steps, nb_problems, layout, convention, xref, uref, weighting, active, A, B, c, Cxx,
-                             cx, Cuu, cu, Cxu, as_stream(stream), nullptr);
+                             cx, Cuu, cu, Cxu, as_stream(stream), nullptr, layout);
 }

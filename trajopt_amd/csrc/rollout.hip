@@ -28,7 +28,9 @@ __device__ __forceinline__ size_t gi(size_t e_total, size_t E_total, size_t p, s
     return MINOR ? e_total * NP + p : p * E_total + e_total;
 }
 
-template <class SYS, bool MINOR>
+// MINOR: layout of x0 / xref / uref / candidates;  KMINOR: layout of the gains K, kff (the batched driver keeps
+// them PROBLEM_MAJOR for the matrix-core backward kernel when dx > 6).
+template <class SYS, bool MINOR, bool KMINOR>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     constexpr int N = SYS::N, M = SYS::M;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,11 +66,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         for (int j = 0; j < M; ++j)
             if (j < m) {
                 ur[j] = a.uref[gi<MINOR>((size_t)m * t + j, Em, p, NP)];
-                kf[j] = a.kff[gi<MINOR>((size_t)m * t + j, Em, p, NP)];
+                kf[j] = a.kff[gi<KMINOR>((size_t)m * t + j, Em, p, NP)];
             }
 #pragma unroll
         for (int k = 0; k < M * N; ++k)
-            if (k < n * m) Kt[k] = a.K[gi<MINOR>((size_t)n * m * t + k, Enm, p, NP)];
+            if (k < n * m) Kt[k] = a.K[gi<KMINOR>((size_t)n * m * t + k, Enm, p, NP)];
     };
     if (T > 0) load(0);
     double w = a.weighting[0];
@@ -151,14 +153,17 @@ __global__ void env_step_kernel(StepArgs s) {
 
 struct RolloutLaunch {
     RolloutArgs a;
-    int layout;
+    int layout, k_layout;
     hipStream_t st;
     template <class SYS>
     void operator()() {
         const size_t total = a.NP * (size_t)a.nb_alphas;
         const dim3 grid((unsigned)((total + 63) / 64)), block(64);
-        if (layout == TRAJOPT_LAYOUT_PROBLEM_MINOR) hipLaunchKernelGGL((rollout_kernel<SYS, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((rollout_kernel<SYS, false>), grid, block, 0, st, a);
+        const bool mi = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR, kmi = k_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
+        if (mi && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true>), grid, block, 0, st, a);
+        else if (mi) hipLaunchKernelGGL((rollout_kernel<SYS, true, false>), grid, block, 0, st, a);
+        else if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((rollout_kernel<SYS, false, false>), grid, block, 0, st, a);
     }
 };
 
@@ -177,14 +182,14 @@ struct StepLaunch {
 int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, const double* x0, const double* K,
                    const double* kff, const double* xref, const double* uref, const double* weighting,
                    const double* alphas_host, int nb_alphas, const int32_t* active, double* state, double* action,
-                   double* cost, double* ret, int32_t* finite, hipStream_t st) {
+                   double* cost, double* ret, int32_t* finite, hipStream_t st, int k_layout) {
     RolloutLaunch L;
     L.a.env = *env;
     L.a.x0 = x0; L.a.K = K; L.a.kff = kff; L.a.xref = xref; L.a.uref = uref; L.a.weighting = weighting;
     L.a.active = active; L.a.state = state; L.a.action = action; L.a.cost = cost; L.a.ret = ret; L.a.finite = finite;
     for (int i = 0; i < TRAJOPT_MAX_ALPHAS; ++i) L.a.alphas[i] = i < nb_alphas ? alphas_host[i] : 0.0;
     L.a.NP = (size_t)NP; L.a.T = T; L.a.nb_alphas = nb_alphas;
-    L.layout = layout; L.st = st;
+    L.layout = layout; L.k_layout = k_layout; L.st = st;
     if (!dispatch_model(*env, L)) return TRAJOPT_ERR_UNSUPPORTED;
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
@@ -205,7 +210,7 @@ int trajopt_ilqr_forward_pass_batched(const trajopt_env_t* env, int nb_steps, in
     if (nb_steps <= 0 || nb_problems <= 0 || nb_alphas <= 0 || nb_alphas > TRAJOPT_MAX_ALPHAS) return TRAJOPT_ERR_BAD_ARG;
     if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
     return launch_rollout(env, nb_steps, nb_problems, layout, x0, K, kff, xref, uref, weighting, alphas_host, nb_alphas,
-                          active, state, action, cost, ret, finite, as_stream(stream));
+                          active, state, action, cost, ret, finite, as_stream(stream), layout);
 }
 
 int trajopt_env_step_batched(const trajopt_env_t* env, const double* x, const double* u, const double* u_last,

@@ -13,8 +13,9 @@ import ctypes as C
 import numpy as np
 
 from .. import _lib
-from .._lib import ILQROptions, ILQRWorkspace, LAYOUT_PROBLEM_MINOR, check, dptr, lib, stream_ptr
-from ..layout import from_device, to_device
+from .._lib import (ILQROptions, ILQRWorkspace, LAYOUT_PROBLEM_MAJOR, LAYOUT_PROBLEM_MINOR, check, dptr, lib,
+                    stream_ptr)
+from ..layout import empty as lempty, from_device, to_device
 from . import core
 from .objects import (AnalyticalLinearDynamics, AnalyticalQuadraticCost, LinearControl, QuadraticStateActionValue,
                       QuadraticStateValue)
@@ -45,14 +46,18 @@ class BatchedILQR:
     (default: 1e-4 * randn from np.random, as ilqr.py:70).  Remaining kwargs as the reference's iLQR.
     argmin_alpha=True picks the lowest-return accepted alpha instead of the reference's first-accept order.
     keep_value=True also maintains vfunc/qfunc (V, v, Qxx, Qux, Quu, qx, qu) of the accepted iterate.
-    Device tensors are exposed as attributes in PROBLEM_MINOR shape (T, cols, rows, N); `.host(name)` returns
-    the logical (N, rows, cols, T) NumPy array.
+    Device tensors are exposed as attributes in PROBLEM_MINOR shape (T, cols, rows, N), except the "gains
+    group" (K, kff, vfunc/qfunc arrays and the quadratisation scratch), whose layout `gains_layout` is chosen for
+    the backward kernel: PROBLEM_MINOR for dm_state <= 6 (lane-per-problem kernel), PROBLEM_MAJOR (N, T, cols, rows)
+    above (matrix-core kernel).  `.host(name)` returns the logical (N, rows, cols, T) NumPy array either way.
     """
+
+    GAINS_GROUP = ("K", "kff", "V", "v", "Qxx", "Qux", "Quu", "qx", "qu")
 
     def __init__(self, env, nb_steps, init_state, kff_init=None, activation=None, slew_rate=False,
                  action_penalty=False, alphas=DEFAULT_ALPHAS, lmbda=1., dlmbda=1., min_lmbda=1e-6, max_lmbda=1e6,
                  mult_lmbda=1.6, tolfun=1e-6, tolgrad=1e-4, min_imp=0., reg=1, argmin_alpha=False,
-                 keep_value=False, trace_cap=None, device=None, apply_env_kwargs=True):
+                 keep_value=False, trace_cap=None, device=None, apply_env_kwargs=True, gains_layout=None):
         import torch
         _lib.require_gpu()
         self.env = env
@@ -78,17 +83,20 @@ class BatchedILQR:
         self.weighting_host = make_weighting(T, activation)
         self._struct = u.struct()
 
+        self.gains_layout = GL = (LAYOUT_PROBLEM_MINOR if n <= 6 else LAYOUT_PROBLEM_MAJOR) \
+            if gains_layout is None else int(gains_layout)
         f64 = dict(dtype=torch.float64, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         z = lambda *s: torch.zeros(s, **f64)
+        zg = lambda *logical: lempty((N,) + logical, GL, dev, zero=True)   # gains group: logical (rows[, cols], T)
         self.x0 = x0.t().contiguous()                      # (n, N)
         self.weighting = torch.as_tensor(self.weighting_host, **f64)
         self.xref, self.uref = z(T + 1, n, N), z(T, m, N)
         self.xref[0] = self.x0                             # ilqr.py:59-60
-        self.K = z(T, n, m, N)
+        self.K = zg(m, n, T)
         if kff_init is None:
             kff_init = 1e-4 * np.random.randn(N, m, T)     # ilqr.py:70 (global NumPy RNG)
-        self.kff = to_device(np.asarray(kff_init, dtype=np.float64).reshape(N, m, T), LAYOUT_PROBLEM_MINOR, dev)
+        self.kff = to_device(np.asarray(kff_init, dtype=np.float64).reshape(N, m, T), GL, dev)
         self.last_return = torch.full((N,), -float("inf"), **f64)   # ilqr.py:87
         self.lmbda = torch.full((N,), float(lmbda), **f64)
         self.dlmbda = torch.full((N,), float(dlmbda), **f64)
@@ -101,21 +109,21 @@ class BatchedILQR:
         self.keep_value = bool(keep_value)
         na = self.alphas.size
         # scratch
-        self._A, self._B = z(T, n, n, N), z(T, m, n, N)
-        self._Cxx, self._cx = z(T + 1, n, n, N), z(T + 1, n, N)
-        self._Cuu, self._cu, self._Cxu = z(T + 1, m, m, N), z(T + 1, m, N), z(T + 1, m, n, N)
-        self._cand_K, self._cand_kff = z(T, n, m, N), z(T, m, N)
+        self._A, self._B = zg(n, n, T), zg(n, m, T)
+        self._Cxx, self._cx = zg(n, n, T + 1), zg(n, T + 1)
+        self._Cuu, self._cu, self._Cxu = zg(m, m, T + 1), zg(m, T + 1), zg(n, m, T + 1)
+        self._cand_K, self._cand_kff = zg(m, n, T), zg(m, T)
         self._dV, self._g_norm = z(2, N), z(N)
         self._diverge, self._active, self._sel = torch.zeros(N, **i32), torch.zeros(N, **i32), torch.zeros(N, **i32)
         self._cand_state, self._cand_action = z(na, T + 1, n, N), z(na, T, m, N)
         self._cand_ret, self._cand_finite = z(na, N), torch.zeros((na, N), **i32)
         if self.keep_value:
-            self.V, self.v = z(T + 1, n, n, N), z(T + 1, n, N)
-            self.Qxx, self.Qux, self.Quu = z(T, n, n, N), z(T, n, m, N), z(T, m, m, N)
-            self.qx, self.qu = z(T, n, N), z(T, m, N)
-            self._cand_V, self._cand_v = z(T + 1, n, n, N), z(T + 1, n, N)
-            self._cand_Qxx, self._cand_Qux, self._cand_Quu = z(T, n, n, N), z(T, n, m, N), z(T, m, m, N)
-            self._cand_qx, self._cand_qu = z(T, n, N), z(T, m, N)
+            self.V, self.v = zg(n, n, T + 1), zg(n, T + 1)
+            self.Qxx, self.Qux, self.Quu = zg(n, n, T), zg(m, n, T), zg(m, m, T)
+            self.qx, self.qu = zg(n, T), zg(m, T)
+            self._cand_V, self._cand_v = zg(n, n, T + 1), zg(n, T + 1)
+            self._cand_Qxx, self._cand_Qux, self._cand_Quu = zg(n, n, T), zg(m, n, T), zg(m, m, T)
+            self._cand_qx, self._cand_qu = zg(n, T), zg(m, T)
 
         o = ILQROptions()
         o.sched.min_lmbda, o.sched.max_lmbda, o.sched.mult_lmbda = float(min_lmbda), float(max_lmbda), float(mult_lmbda)
@@ -131,6 +139,7 @@ class BatchedILQR:
     def _make_ws(self):
         w = ILQRWorkspace()
         w.nb_steps, w.nb_problems, w.trace_cap = self.nb_steps, self.nb_problems, self.trace_cap
+        w.gains_layout = self.gains_layout
         pub = ("x0", "weighting", "xref", "uref", "K", "kff", "last_return", "lmbda", "dlmbda", "alpha", "status",
                "iters", "trace_len", "trace")
         for k in pub:
@@ -182,6 +191,9 @@ class BatchedILQR:
         ret = torch.empty((na, N), **f64)
         finite = torch.empty((na, N), dtype=torch.int32, device=self.device)
         arr = (C.c_double * na)(*[float(a) for a in al])
+        if self.gains_layout != LAYOUT_PROBLEM_MINOR:  # the public rollout entry takes one layout for everything
+            K = to_device(from_device(K, self.gains_layout), LAYOUT_PROBLEM_MINOR, self.device)
+            kff = to_device(from_device(kff, self.gains_layout), LAYOUT_PROBLEM_MINOR, self.device)
         check(lib().trajopt_ilqr_forward_pass_batched(
             C.byref(self._struct), T, C.c_int64(N), LAYOUT_PROBLEM_MINOR, dptr(self.x0), dptr(K), dptr(kff),
             dptr(self.xref), dptr(self.uref), dptr(self.weighting), arr, na, None, dptr(state), dptr(action),
@@ -193,7 +205,7 @@ class BatchedILQR:
         t = getattr(self, name)
         if t.dim() == 1:
             return t.cpu().numpy()
-        return from_device(t, LAYOUT_PROBLEM_MINOR)
+        return from_device(t, self.gains_layout if name in self.GAINS_GROUP else LAYOUT_PROBLEM_MINOR)
 
 
 class iLQR:
@@ -250,7 +262,7 @@ class iLQR:
         b.weighting.copy_(b.weighting.new_tensor(self.weighting))
         import torch
         L = LAYOUT_PROBLEM_MINOR
-        b.K.copy_(to_device(np.asarray(self.ctl.K, dtype=np.float64)[None], L, b.device))
+        b.K.copy_(to_device(np.asarray(self.ctl.K, dtype=np.float64)[None], b.gains_layout, b.device))
         b.xref.copy_(to_device(np.asarray(self.xref, dtype=np.float64)[None], L, b.device))
         b.uref.copy_(to_device(np.asarray(self.uref, dtype=np.float64)[None], L, b.device))
         b.last_return.fill_(float(self.last_return))
@@ -260,8 +272,8 @@ class iLQR:
         """-> state (dm_state, T+1), action (dm_act, T), cost (T+1,)   (ilqr.py:89-102)"""
         b = self._batched()
         L = LAYOUT_PROBLEM_MINOR
-        K = to_device(np.asarray(ctl.K, dtype=np.float64)[None], L, b.device)
-        kff = to_device(np.asarray(ctl.kff, dtype=np.float64)[None], L, b.device)
+        K = to_device(np.asarray(ctl.K, dtype=np.float64)[None], b.gains_layout, b.device)
+        kff = to_device(np.asarray(ctl.kff, dtype=np.float64)[None], b.gains_layout, b.device)
         state, action, cost, _, _ = b.forward_pass(K, kff, alphas=[alpha])
         return (np.ascontiguousarray(from_device(state[0], L)[0]), np.ascontiguousarray(from_device(action[0], L)[0]),
                 cost[0, :, 0].cpu().numpy())
