@@ -216,7 +216,8 @@ def test_host_entry_point_is_the_reference_signature(oracle):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
-@pytest.mark.parametrize("n,m,T,N", [(2, 1, 60, 3), (4, 1, 40, 5), (6, 2, 30, 4), (12, 4, 24, 3), (64, 16, 5, 2)])
+@pytest.mark.parametrize("n,m,T,N", [(2, 1, 60, 3), (4, 1, 40, 5), (6, 2, 30, 4), (12, 4, 24, 3), (64, 16, 5, 2),
+                                      (17, 1, 9, 3), (33, 7, 9, 3), (48, 16, 7, 2), (64, 16, 30, 3), (50, 3, 11, 2)])
 def test_riccati_backward_matches_oracle(oracle, n, m, T, N, layout):
     import torch
     from trajopt_amd import backward, layout as L, synthetic as S

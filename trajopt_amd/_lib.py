@@ -88,6 +88,12 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise TrajoptError(
                 "%s is missing: build it with `make -C trajopt_amd/csrc` (there is no CPU fallback)" % SO_PATH)
+        # torch ships its own libamdhip64; it must be the first HIP runtime in the process: loaded after the
+        # system one (which this library would pull in) torch.cuda.is_available() turns False
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(SO_PATH)
         L.trajopt_error_string.restype = C.c_char_p
         L.trajopt_last_hip_error.restype = C.c_char_p

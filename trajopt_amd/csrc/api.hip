@@ -120,6 +120,12 @@ int trajopt_riccati_backward_pass_batched(const double* Cxx, const double* cx, c
     if (!Cxx || !cx || !Cuu || !cu || !Cxu || !A || !B || !c || !V || !v || !K || !kff) return TRAJOPT_ERR_BAD_ARG;
     if (n <= 0 || m <= 0 || T <= 0 || NP <= 0) return TRAJOPT_ERR_BAD_ARG;
     if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
+    if (g_force_kernel == 0 || g_force_kernel == 2) {  // tiled matrix-core kernel (16 < dx <= 64, PROBLEM_MAJOR)
+        bool handled = false;
+        const int rc = launch_riccati_mfma64(Cxx, cx, Cuu, cu, Cxu, A, B, c, n, m, T, NP, layout, V, v, K, kff, status,
+                                             as_stream(stream), &handled);
+        if (rc != TRAJOPT_OK || handled) return rc;
+    }
     return launch_riccati_wg(Cxx, cx, Cuu, cu, Cxu, A, B, c, n, m, T, NP, layout, V, v, K, kff, status,
                              as_stream(stream));
 }

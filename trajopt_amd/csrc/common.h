@@ -41,4 +41,9 @@ int launch_riccati_wg(const double* Cxx, const double* cx, const double* Cuu, co
                       const double* A, const double* B, const double* c, int n, int m, int T, int64_t NP,
                       int layout, double* V, double* v, double* K, double* kff, int32_t* status, hipStream_t st);
 
+int launch_riccati_mfma64(const double* Cxx, const double* cx, const double* Cuu, const double* cu, const double* Cxu,
+                          const double* A, const double* B, const double* c, int n, int m, int T, int64_t NP,
+                          int layout, double* V, double* v, double* K, double* kff, int32_t* status, hipStream_t st,
+                          bool* handled);
+
 }  // namespace trajopt

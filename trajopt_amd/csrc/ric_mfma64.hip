@@ -1,0 +1,364 @@
+// Workgroup-per-problem time-varying LQR Riccati sweep on the fp64 matrix cores, for 16 < dx <= 64, du <= 16
+// (BASELINE config C5: dx = 64, du = 16, T = 1000, 1024 problems).
+//
+// Row A9 of the hot path: /root/reference/trajopt/riccati/riccati.py:100-126 ("no-1/2, affine-c" convention),
+// with V = Qxx + Qux' K as a matrix product.
+//
+// The state dimension is cut into 16 x 16 tiles of v_mfma_f64_16x16x4_f64; F = [A B] is (4 x 5) tiles.  A
+// workgroup is four waves; wave w owns BLOCK COLUMN w of the value function:
+//   Ph1  P(w, :) = V'(w, :) F          wave w needs row strip w of V', which (V' symmetric) is the D-layout image of
+//                                      its own block column: V' never leaves the registers (riccati.py:108-110)
+//   Ph2  Q(:, w) = C(:, w) + F' P(:, w) Qxx block column w, Qux tile w, and a quarter of Quu = Cuu + B'V'B
+//   Ph3  Quu = L D L', K = -Quu^-1 Qux (lane = column), kff = -1/2 Quu^-1 qu                  (riccati.py:118-121)
+//   Ph4  V(:, w) = Qxx(:, w) + K' Qux(w) (= (Qux' K)(:, w) by symmetry), v = qx + 2 Qux' kff   (riccati.py:123-124)
+// F_t is staged in LDS once per step (B operands and, for F', A operands are read from there), P is exchanged
+// through LDS, everything else stays in registers.  The loads of step t-1 are issued at the top of step t.
+//
+// Preconditions (otherwise use the generic kernel, bwd_wg.hip): PROBLEM_MAJOR layout; Cxx symmetric to round-off,
+// as a Hessian is (the block-column trick reads V' as its own transpose); Quu positive definite - a non-positive
+// pivot is reported through status[p] = t + 1 exactly like a singular Quu, whereas np.linalg.inv (riccati.py:118)
+// would also invert an indefinite one.
+#include "smallmat.h"
+
+namespace trajopt {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct Ric64Args {
+    const double *Cxx, *cx, *Cuu, *cu, *Cxu, *A, *B, *c;
+    double *V, *v, *K, *kff;
+    int32_t* status;
+    int n, m, T;
+};
+
+constexpr int kLdk = 66;   // column stride (doubles) of the LDS images of F and P: conflict-free B-operand reads
+constexpr int kLd16 = 17;  // column stride of the 16-row LDS images (Qux, K, Quu partials, L)
+
+struct Ric64Lds {
+    double F[81 * kLdk];       // [col][k]: cols 0..63 = A, 64..79 = B, 80 = c
+    double P[64 * kLdk];       // [col][k]: P = V' A   (the B block column of P stays in registers)
+    double Qux[64 * kLd16];    // Qux[i][j] at i + 17 j
+    double K[64 * kLd16];      // K[i][j]   at i + 17 j
+    double QuuP[4][16 * kLd16];  // per-wave partial sums of Quu, (row, col) at row + 17 col
+    double L[4][16 * kLd16];   // per-wave copy of the unit lower factor, L[i][k] at i * 17 + k
+    double w[64], qx[64], qu[16], kff[16];
+};
+
+__device__ __forceinline__ double bcast_lane(double x, int lane) {  // lane is wave-uniform
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double xor_sum16(double x) {  // sum over lanes c, c+16, c+32, c+48
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Ric64Lds& S = *reinterpret_cast<Ric64Lds*>(smem_raw);
+    const int n = a.n, m = a.m, T = a.T;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const size_t p = blockIdx.x;
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
+    const double* gA = a.A + p * nn * T;
+    const double* gB = a.B + p * nm * T;
+    const double* gc = a.c + p * (size_t)n * T;
+    const double* gCxx = a.Cxx + p * nn * (T + 1);
+    const double* gCxu = a.Cxu + p * nm * (T + 1);
+    const double* gCuu = a.Cuu + p * mm * (T + 1);
+    const double* gcx = a.cx + p * (size_t)n * (T + 1);
+    const double* gcu = a.cu + p * (size_t)m * (T + 1);
+    double* oV = a.V + p * nn * (T + 1);
+    double* ov = a.v + p * (size_t)n * (T + 1);
+    double* oK = a.K + p * nm * T;
+    double* okff = a.kff + p * (size_t)m * T;
+
+    // ---- staging map of F_t = [A_t B_t c_t]: thread-private slots, fixed for the whole sweep -----------------
+    int offA[16], offB[4];
+    bool okA[16], okB[4];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int idx = tid + 256 * s;
+        okA[s] = idx < (int)nn;
+        const int col = okA[s] ? idx / n : 0, k = okA[s] ? idx % n : 0;
+        offA[s] = col * kLdk + k;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int idx = tid + 256 * s;
+        okB[s] = idx < (int)nm;
+        const int col = okB[s] ? idx / n : 0, k = okB[s] ? idx % n : 0;
+        offB[s] = (64 + col) * kLdk + k;
+    }
+    const bool okc = tid < n;
+    double fA[16], fB[4], fc;
+    auto fetch_F = [&](int t) {  // global -> registers (unconditional: masked slots re-read element 0)
+        const double* pa = gA + nn * (size_t)t;
+        const double* pb = gB + nm * (size_t)t;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) fA[s] = pa[okA[s] ? tid + 256 * s : 0];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fB[s] = pb[okB[s] ? tid + 256 * s : 0];
+        fc = gc[(size_t)n * t + (okc ? tid : 0)];
+    };
+    auto stage_F = [&]() {       // registers -> LDS
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (okA[s]) S.F[offA[s]] = fA[s];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (okB[s]) S.F[offB[s]] = fB[s];
+        if (okc) S.F[80 * kLdk + tid] = fc;
+    };
+
+    // zero the padding of the F image once (valid entries are overwritten every step), P needs none
+    for (int i = tid; i < 81 * kLdk; i += 256) S.F[i] = 0.0;
+    __syncthreads();
+    fetch_F(T - 1);
+    stage_F();
+
+    // ---- terminal condition (riccati.py:104-105): block column w of V, own segment of v ----------------------
+    const int col = 16 * w + c;          // the state index this lane owns as a column
+    const bool colok = col < n;
+    d4 Vt[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * kt + g + 4 * r;
+            double x = 0.0;
+            if (colok && row < n) {
+                x = gCxx[nn * (size_t)T + col + (size_t)n * row];  // (symmetric) read along the contiguous index
+                oV[nn * (size_t)T + col + (size_t)n * row] = x;
+            }
+            Vt[kt][r] = x;
+        }
+    double vown = colok ? gcx[(size_t)n * T + col] : 0.0;
+    if (g == 0 && colok) ov[(size_t)n * T + col] = vown;
+    __syncthreads();
+
+    int bad = -1;
+    for (int t = T - 1; t >= 0; --t) {
+        // ================= Ph1: prefetch, w = 2 V'c + v', P = V' F ==========================================
+        fetch_F(t >= 1 ? t - 1 : 0);
+        d4 Q[5];
+#pragma unroll
+        for (int I = 0; I < 4; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + g + 4 * r;
+                const bool ok = colok && row < n;
+                const double x = gCxx[nn * (size_t)t + (ok ? col + (size_t)n * row : 0)];
+                Q[I][r] = ok ? x : 0.0;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // Qux tile starts from Cxu'  (riccati.py:110): element (i, col) = Cxu[col][i]
+            const int i = g + 4 * r;
+            const bool ok = colok && i < m;
+            const double x = gCxu[nm * (size_t)t + (ok ? col + (size_t)n * i : 0)];
+            Q[4][r] = ok ? x : 0.0;
+        }
+        d4 qp = {0.0, 0.0, 0.0, 0.0};  // this wave's part of Quu; wave 0 starts from Cuu
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = g + 4 * r;
+            const bool ok = w == 0 && i < m && c < m;
+            const double x = gCuu[mm * (size_t)t + (ok ? i + (size_t)m * c : 0)];
+            qp[r] = ok ? x : 0.0;
+        }
+        double cq = 0.0;  // cx / cu element for the q vectors (threads 0..159, two per column)
+        {
+            const int qc = tid >> 1;
+            if (tid < 160) {
+                const bool isx = qc < 64;
+                const bool ok = isx ? qc < n : (qc - 64) < m;
+                const double x = isx ? gcx[(size_t)n * t + (ok ? qc : 0)] : gcu[(size_t)m * t + (ok ? qc - 64 : 0)];
+                cq = ok ? x : 0.0;
+            }
+        }
+        {
+            double vc = 0.0;  // (V'c)[col] = sum_k V'[col][k] c[k], k = 16 kt + 4 s + g on this lane
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) vc = fma(Vt[kt][s], S.F[80 * kLdk + 16 * kt + 4 * s + g], vc);
+            vc = xor_sum16(vc);
+            if (g == 0) S.w[col] = fma(2.0, vc, vown);  // riccati.py:112-116
+        }
+        d4 Pw4;
+#pragma unroll
+        for (int J = 0; J < 5; ++J) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[kt][s], S.F[(16 * J + c) * kLdk + 16 * kt + 4 * s + g], acc,
+                                                               0, 0, 0);
+            if (J < 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S.P[(16 * J + c) * kLdk + 16 * w + g + 4 * r] = acc[r];
+            } else {
+                Pw4 = acc;
+            }
+        }
+        __syncthreads();
+
+        // ================= Ph2: Q(:, w) = C(:, w) + F' P(:, w), Quu part, q vectors ===========================
+        {
+            d4 Pc[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Pc[kt][s] = S.P[(16 * w + c) * kLdk + 16 * kt + 4 * s + g];
+#pragma unroll
+            for (int I = 0; I < 5; ++I)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.F[(16 * I + c) * kLdk + 16 * kt + 4 * s + g], Pc[kt][s],
+                                                                    Q[I], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qp = __builtin_amdgcn_mfma_f64_16x16x4f64(S.F[(64 + c) * kLdk + 16 * w + 4 * s + g], Pw4[s], qp, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            S.QuuP[w][(g + 4 * r) + kLd16 * c] = qp[r];
+            S.Qux[(g + 4 * r) + kLd16 * col] = Q[4][r];
+        }
+        if (tid < 160) {  // [qx; qu] = [cx; cu] + F' w   (riccati.py:112-116)
+            const int qc = tid >> 1, half = tid & 1;
+            const double* fcol = &S.F[qc * kLdk + 32 * half];
+            const double* wv = &S.w[32 * half];
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 32; k += 2) {
+                s0 = fma(fcol[k], wv[k], s0);
+                s1 = fma(fcol[k + 1], wv[k + 1], s1);
+            }
+            double sum = s0 + s1;
+            sum += __shfl_xor(sum, 1, 64);
+            if (half == 0) {
+                if (qc < 64) S.qx[qc] = cq + sum;
+                else S.qu[qc - 64] = cq + sum;
+            }
+        }
+        __syncthreads();
+
+        // ================= Ph3: Quu = L D L' (every wave, redundantly), K (wave 0), kff (wave 1) ==============
+        stage_F();  // the F image of this step is dead: bring in step t - 1
+        double row[16], invd[16];
+        bool ok = true;
+        {
+            const int r = c;  // lane holds row r of Quu (replicated over g); rows/cols >= m are identity padding
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double x = 0.0;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) x += S.QuuP[ww][r + kLd16 * j];
+                row[j] = (r < m && j < m) ? x : (r == j ? 1.0 : 0.0);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const double dk = bcast_lane(row[k], k);
+                ok = ok && (dk > 0.0);
+                const double ik = rcp_nr(dk);
+                invd[k] = ik;
+                const double l = (r > k) ? row[k] * ik : 0.0;
+#pragma unroll
+                for (int j = k + 1; j < 16; ++j) row[j] = fma(-l, bcast_lane(row[j], k), row[j]);
+                if (r > k) row[k] = l;
+            }
+            if (g == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) S.L[w][r * kLd16 + k] = row[k];
+            }
+        }
+        if (!ok) {  // identical in every wave: block-uniform exit
+            bad = t;
+            break;
+        }
+        if (w < 2) {
+            double y[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y[i] = (w == 0) ? S.Qux[i + kLd16 * lane] : S.qu[i];
+            const double* Lw = S.L[w];
+#pragma unroll
+            for (int i = 1; i < 16; ++i)
+#pragma unroll
+                for (int k = 0; k < i; ++k) y[i] = fma(-Lw[i * kLd16 + k], y[k], y[i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y[i] *= invd[i];
+#pragma unroll
+            for (int i = 14; i >= 0; --i)
+#pragma unroll
+                for (int k = i + 1; k < 16; ++k) y[i] = fma(-Lw[k * kLd16 + i], y[k], y[i]);
+            if (w == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S.K[i + kLd16 * lane] = -y[i];  // riccati.py:120
+            } else if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S.kff[i] = -0.5 * y[i];         // riccati.py:121
+            }
+        }
+        __syncthreads();
+
+        // ================= Ph4: V(:, w) = Qxx(:, w) + K' Qux(w), v = qx + 2 Qux' kff, outputs ================
+#pragma unroll
+        for (int I = 0; I < 4; ++I)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.K[(4 * s + g) + kLd16 * (16 * I + c)], Q[4][s], Q[I], 0, 0, 0);
+        {
+            double part = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part = fma(Q[4][r], S.kff[g + 4 * r], part);
+            part = xor_sum16(part);
+            vown = colok ? fma(2.0, part, S.qx[col]) : 0.0;  // riccati.py:124
+        }
+#pragma unroll
+        for (int I = 0; I < 4; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rw = 16 * I + g + 4 * r;
+                const bool okv = colok && rw < n;
+                const double x = okv ? Q[I][r] : 0.0;  // padding stays exactly zero
+                Vt[I][r] = x;
+                if (okv) oV[nn * (size_t)t + col + (size_t)n * rw] = x;  // V' = V: stored along the contiguous index
+            }
+        if (g == 0 && colok) ov[(size_t)n * t + col] = vown;
+        for (int idx = tid; idx < (int)nm; idx += 256) {
+            const int i = idx % m, j = idx / m;
+            oK[nm * (size_t)t + idx] = S.K[i + kLd16 * j];
+        }
+        if (tid < m) okff[(size_t)m * t + tid] = S.kff[tid];
+    }
+    if (tid == 0 && a.status) a.status[p] = bad < 0 ? 0 : bad + 1;
+}
+
+// handled = false when the shape / layout is outside this kernel's range.
+int launch_riccati_mfma64(const double* Cxx, const double* cx, const double* Cuu, const double* cu, const double* Cxu,
+                          const double* A, const double* B, const double* c, int n, int m, int T, int64_t NP,
+                          int layout, double* V, double* v, double* K, double* kff, int32_t* status, hipStream_t st,
+                          bool* handled) {
+    *handled = false;
+    if (n <= 16 || n > 64 || m < 1 || m > 16) return TRAJOPT_OK;
+    if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && NP != 1) return TRAJOPT_OK;
+    if (NP > 0x7fffffff) return TRAJOPT_OK;
+    *handled = true;
+    Ric64Args a{Cxx, cx, Cuu, cu, Cxu, A, B, c, V, v, K, kff, status, n, m, T};
+    const size_t lds = sizeof(Ric64Lds);
+    TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)ric_mfma64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+    hipLaunchKernelGGL(ric_mfma64_kernel, dim3((unsigned)NP), dim3(256), lds, st, a);
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+}  // namespace trajopt
