@@ -78,41 +78,41 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
     double* okff = a.kff + p * (size_t)m * T;
 
     // ---- staging map of F_t = [A_t B_t c_t]: thread-private slots, fixed for the whole sweep -----------------
-    int offA[16], offB[4];
-    bool okA[16], okB[4];
+    // Slots beyond the matrix re-read element 0 and are parked in a pad word that nothing reads (k = 64 of col 0):
+    // no per-slot predicates (20 of them as SGPR pairs made hipcc spill scalars through v_writelane).
+    constexpr int kPark = 64;
+    int srcA[16], offA[16], srcB[4], offB[4];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const int idx = tid + 256 * s;
-        okA[s] = idx < (int)nn;
-        const int col = okA[s] ? idx / n : 0, k = okA[s] ? idx % n : 0;
-        offA[s] = col * kLdk + k;
+        const bool ok = idx < (int)nn;
+        srcA[s] = ok ? idx : 0;
+        offA[s] = ok ? (idx / n) * kLdk + idx % n : kPark;
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int idx = tid + 256 * s;
-        okB[s] = idx < (int)nm;
-        const int col = okB[s] ? idx / n : 0, k = okB[s] ? idx % n : 0;
-        offB[s] = (64 + col) * kLdk + k;
+        const bool ok = idx < (int)nm;
+        srcB[s] = ok ? idx : 0;
+        offB[s] = ok ? (64 + idx / n) * kLdk + idx % n : kPark;
     }
-    const bool okc = tid < n;
+    const int srcc = tid < n ? tid : 0, offc = tid < n ? 80 * kLdk + tid : kPark;
     double fA[16], fB[4], fc;
-    auto fetch_F = [&](int t) {  // global -> registers (unconditional: masked slots re-read element 0)
+    auto fetch_F = [&](int t) {  // global -> registers, unconditional
         const double* pa = gA + nn * (size_t)t;
         const double* pb = gB + nm * (size_t)t;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) fA[s] = pa[okA[s] ? tid + 256 * s : 0];
+        for (int s = 0; s < 16; ++s) fA[s] = pa[srcA[s]];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) fB[s] = pb[okB[s] ? tid + 256 * s : 0];
-        fc = gc[(size_t)n * t + (okc ? tid : 0)];
+        for (int s = 0; s < 4; ++s) fB[s] = pb[srcB[s]];
+        fc = gc[(size_t)n * t + srcc];
     };
     auto stage_F = [&]() {       // registers -> LDS
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
-            if (okA[s]) S.F[offA[s]] = fA[s];
+        for (int s = 0; s < 16; ++s) S.F[offA[s]] = fA[s];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            if (okB[s]) S.F[offB[s]] = fB[s];
-        if (okc) S.F[80 * kLdk + tid] = fc;
+        for (int s = 0; s < 4; ++s) S.F[offB[s]] = fB[s];
+        S.F[offc] = fc;
     };
 
     // zero the padding of the F image once (valid entries are overwritten every step), P needs none
