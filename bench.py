@@ -99,12 +99,22 @@ def main():
         raise SystemExit("for --gpus > 1 launch with python -m torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local)
+    # one process per GPU; TRAJOPT_BENCH_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the
+    # multi-rank path on a single-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("TRAJOPT_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local >= ndev:
+        raise SystemExit("rank %d has no GPU (%d visible)" % (local, ndev))
+    torch.cuda.set_device(local % ndev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from trajopt_amd import _lib, envs
     from trajopt_amd.ilqr import BatchedILQR
@@ -139,7 +149,7 @@ def main():
     _lib.check(L.trajopt_profile_end(phase_ms, C.byref(nrec)))
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -156,6 +166,16 @@ def main():
         per_launch = ab[dom] * N * T
         achieved = per_launch / (phases[dom] * 1e-3) / 1e9
         bwd_gbs = ab["backward"] * N * T / (phases["backward"] * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
+        # separate runs, gfx950 read correction applied; profiles/r01_pmc_traffic_c2.json) - PMC counters cannot
+        # be sampled from inside this process, so it is only filled for the workload they were collected on
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_c2.json")))
+            if a.env == "cartpole" and N == 4096 and T == 500 and nb_alphas == 11:
+                traffic = pmc["by_phase"].get(dom)
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out = {
             "metric": "problem-timesteps/sec (iLQR iteration, batched)",
             "value": world * N * T * K / elapsed,
@@ -168,7 +188,7 @@ def main():
                                    "stopping rules disabled" % (a.env, n, m, T, N, nb_alphas),
                        "instances_per_gpu": N, "horizon": T, "parallelism": "problems sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": per_launch, "avg_launch_ms": phases[dom]},
             "phase_ms": phases,
             "backward_pass_GBps": bwd_gbs,
