@@ -299,3 +299,29 @@ def test_riccati_class_on_the_lqr_env_reaches_the_dare_gain(oracle):
     Kinf = -np.linalg.solve(R + B.T @ P @ B, B.T @ P @ A)
     np.testing.assert_allclose(solver.ctl.K[..., 0], Kinf, rtol=1e-9)
     np.testing.assert_allclose(solver.vfunc.V[..., 0], P, rtol=1e-8)  # scipy DARE accuracy
+
+
+def test_batched_mpc_matches_the_reference_loop(oracle):
+    """examples/ilqr/mpc/pendulum.py:18-31 for N systems at once: a fresh horizon solve per control step, apply
+    uref[:, 0], step the plant.  Checked against the same loop on the oracle (deterministic plant + injected noise)."""
+    from trajopt_amd import envs
+    from trajopt_amd.mpc import BatchedMPC
+    N, horizon, steps, iters = 9, 20, 6, 5
+    rng = np.random.Generator(np.random.PCG64(7))
+    env = envs.make("Pendulum-TO-v0")
+    env.unwrapped.dt = 0.05
+    x0 = np.array([np.pi, 0.])[None] + 0.05 * rng.standard_normal((N, 2))
+    kff = 1e-4 * rng.standard_normal((steps, N, 1, horizon))
+    noise = 1e-3 * rng.standard_normal((N, 2, steps))
+    mpc = BatchedMPC(env, horizon, x0, nb_iter=iters, action_penalty=np.array([1e-5]))
+    out = mpc.run(steps, process_noise=noise, kff_inits=kff)
+    oe = oracle.make_env("pendulum", dt=0.05, uw=[1e-5])
+    for p in range(N):
+        x = x0[p].copy()
+        for t in range(steps):
+            r = oracle.ilqr_run(oe, horizon, x, kff[t, p], nb_iter=iters)
+            u = r["uref"][:, 0]
+            assert_close(out["state"][p, :, t], x, "state[%d,%d]" % (p, t), tol=1e-7)
+            assert abs(out["action"][p, 0, t] - u[0]) <= 1e-7 * max(1.0, abs(u[0])), (p, t)
+            assert abs(out["cost"][p, t] - r["last_return"]) <= 1e-8 * abs(r["last_return"])
+            x = oracle.env_dynamics(oe, x, u) + noise[p, :, t]

@@ -135,6 +135,39 @@ class BatchedILQR:
         self._opt = o
         self._ws = self._make_ws()
         self._initialised = False
+        self._lmbda0, self._dlmbda0 = float(lmbda), float(dlmbda)
+
+    def reset(self, init_state, kff_init=None):
+        """Re-arm the solver for new initial states without reallocating anything: the state a FRESH
+        iLQR(env, nb_steps, init_state) would have (ilqr.py:59-70,87) - the reference's MPC loops build a new
+        solver at every control step (examples/ilqr/mpc/pendulum.py:22-27).  init_state: (N, dm_state) array or
+        device tensor; kff_init as in the constructor."""
+        import torch
+        N, n, m, T = self.nb_problems, self.dm_state, self.dm_act, self.nb_steps
+        if torch.is_tensor(init_state):
+            x0 = init_state.detach().to(device=self.device, dtype=torch.float64).reshape(N, n)
+        else:
+            x0 = torch.as_tensor(np.asarray(init_state, dtype=np.float64).reshape(N, n), device=self.device)
+        self.x0.copy_(x0.t())
+        self.xref.zero_()
+        self.xref[0] = self.x0
+        self.uref.zero_()
+        self.K.zero_()
+        if kff_init is None:
+            kff_init = 1e-4 * np.random.randn(N, m, T)
+        if torch.is_tensor(kff_init):
+            self.kff.copy_(kff_init.reshape(self.kff.shape))
+        else:
+            self.kff.copy_(to_device(np.asarray(kff_init, dtype=np.float64).reshape(N, m, T), self.gains_layout,
+                                     self.device))
+        self.last_return.fill_(-float("inf"))
+        self.lmbda.fill_(self._lmbda0)
+        self.dlmbda.fill_(self._dlmbda0)
+        self.alpha.fill_(float("nan"))
+        self.status.zero_()
+        self.iters.zero_()
+        self.trace_len.zero_()
+        self._initialised = False
 
     def _make_ws(self):
         w = ILQRWorkspace()
