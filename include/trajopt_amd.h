@@ -182,6 +182,14 @@ typedef struct trajopt_ilqr_options {
     double alphas[TRAJOPT_MAX_ALPHAS];  /* ilqr.py:15 */
     int32_t argmin_alpha;  /* 0 = reference's first-accept order (ilqr.py:187-202); 1 = lowest return among accepted */
     int32_t keep_value;    /* 1 = also maintain vfunc/qfunc (V, v, Qxx, Qux, Quu, qx, qu) on accept    */
+    /* Line-search scheduling (results are identical either way):
+     *   0 = every alpha of every problem in one launch (shortest latency: small batches);
+     *   1 = staged like the reference's sequential loop (ilqr.py:187-202): alphas[0] for everybody, then the
+     *       remaining alphas only for the problems that rejected it, compacted so that waves stay full (needs
+     *       ws->pending_list / ws->pending_count; ignored with argmin_alpha);
+     *  -1 = pick by batch size. */
+    int32_t staged_line_search;
+    int32_t pad_;
 } trajopt_ilqr_options_t;
 
 typedef struct trajopt_ilqr_workspace {
@@ -216,6 +224,8 @@ typedef struct trajopt_ilqr_workspace {
     int32_t* sel;                        /* [nb_problems] index of the accepted alpha, -1 = none       */
     double* cand_state; double* cand_action; double* cand_ret;   /* [nb_alphas] candidates            */
     int32_t* cand_finite;
+    int32_t* pending_list;   /* [nb_problems], staged line search only (may be NULL otherwise) */
+    int32_t* pending_count;  /* [1] */
 } trajopt_ilqr_workspace_t;
 
 /* ilqr.py:139-149: initial rollout of ws->K / ws->kff over the alphas; first one with all(state < 1e8)

@@ -325,3 +325,30 @@ def test_batched_mpc_matches_the_reference_loop(oracle):
             assert abs(out["action"][p, 0, t] - u[0]) <= 1e-7 * max(1.0, abs(u[0])), (p, t)
             assert abs(out["cost"][p, t] - r["last_return"]) <= 1e-8 * abs(r["last_return"])
             x = oracle.env_dynamics(oe, x, u) + noise[p, :, t]
+
+
+@pytest.mark.parametrize("name,kw", [("cartpole", dict(dt=0.02)), ("pendulum", dict(dt=0.05))])
+def test_staged_line_search_is_bitwise_the_one_launch_line_search(oracle, name, kw):
+    """Scheduling only: alphas[0] for everybody, the rest for the compacted list of rejecting problems
+    (the reference's sequential first-accept loop, ilqr.py:187-202) must give the same numbers as rolling every
+    alpha out at once."""
+    from trajopt_amd import envs
+    from trajopt_amd.ilqr import BatchedILQR
+    rng = np.random.default_rng(21)
+    N, T = 300, 60
+    env0 = envs.make(name, **kw)
+    x0 = np.asarray(env0.x0)[None] + 0.3 * rng.standard_normal((N, env0.dm_state))
+    kff0 = 1e-4 * rng.standard_normal((N, env0.dm_act, T))
+    res = []
+    for staged in (0, 1):
+        env = envs.make(name, **kw)
+        s = BatchedILQR(env, T, x0, kff_init=kff0, action_penalty=1e-5, staged_line_search=staged)
+        s.run(nb_iter=6)
+        res.append({k: s.host(k).copy() for k in ("xref", "uref", "K", "kff", "last_return", "lmbda", "alpha", "status")})
+    assert len(np.unique(res[0]["alpha"])) > 1, "the case must exercise alphas beyond the first"
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k], equal_nan=True), k
+    oe = oracle.make_env(name, dt=kw["dt"], uw=[1e-5])
+    for p in range(0, N, 37):
+        r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=6)
+        assert abs(res[1]["last_return"][p] - r["last_return"]) <= TOL * abs(r["last_return"])

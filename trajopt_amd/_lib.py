@@ -54,7 +54,8 @@ class BackwardIO(C.Structure):
 class ILQROptions(C.Structure):
     _fields_ = [("sched", LambdaSchedule), ("tolfun", C.c_double), ("tolgrad", C.c_double),
                 ("min_imp", C.c_double), ("reg", C.c_int32), ("nb_alphas", C.c_int32),
-                ("alphas", C.c_double * MAX_ALPHAS), ("argmin_alpha", C.c_int32), ("keep_value", C.c_int32)]
+                ("alphas", C.c_double * MAX_ALPHAS), ("argmin_alpha", C.c_int32), ("keep_value", C.c_int32),
+                ("staged_line_search", C.c_int32), ("pad_", C.c_int32)]
 
 
 class ILQRWorkspace(C.Structure):
@@ -66,7 +67,7 @@ class ILQRWorkspace(C.Structure):
                 [(k, _dp) for k in
                  ("A", "B", "Cxx", "cx", "Cuu", "cu", "Cxu", "cand_K", "cand_kff", "cand_V", "cand_v", "cand_Qxx",
                   "cand_Qux", "cand_Quu", "cand_qx", "cand_qu", "dV", "g_norm", "diverge", "active", "sel",
-                  "cand_state", "cand_action", "cand_ret", "cand_finite")])
+                  "cand_state", "cand_action", "cand_ret", "cand_finite", "pending_list", "pending_count")])
 
 
 # every symbol include/trajopt_amd.h declares

@@ -14,7 +14,8 @@ namespace trajopt {
 int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, const double* x0, const double* K,
                    const double* kff, const double* xref, const double* uref, const double* weighting,
                    const double* alphas_host, int nb_alphas, const int32_t* active, double* state, double* action,
-                   double* cost, double* ret, int32_t* finite, hipStream_t st, int k_layout);
+                   double* cost, double* ret, int32_t* finite, hipStream_t st, int k_layout, int alpha_begin,
+                   int alpha_end, const int32_t* plist, const int32_t* pcount);
 struct QuadCommit {  // fused commit of the previous line search inside the quadratisation (quadratize.hip)
     const int32_t* sel;
     const double *cand_state, *cand_action, *cand_K, *cand_kff;
@@ -84,6 +85,23 @@ __global__ void post_backward_kernel(DrvArgs a) {
     }
     a.ws.lmbda[p] = lam;
     a.ws.dlmbda[p] = dlam;
+}
+
+// Staged line search, stage 1 -> 2: problems whose first alpha is rejected (ilqr.py:196-202) are appended to a
+// compact list; only they roll out the remaining alphas.  List order depends on the atomics' arrival order, the
+// per-problem results do not.
+__global__ void pending_kernel(DrvArgs a) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t NP = (size_t)a.ws.nb_problems;
+    if (p >= NP) return;
+    if (!a.ws.active[p]) return;
+    const double alpha = a.opt.alphas[0];
+    const double dret = a.ws.last_return[p] - a.ws.cand_ret[p];
+    const double expected = -1.0 * alpha * (a.ws.dV[p] + alpha * a.ws.dV[NP + p]);
+    if (!(dret / expected >= a.opt.min_imp)) {
+        const int j = atomicAdd(a.ws.pending_count, 1);
+        a.ws.pending_list[j] = (int32_t)p;
+    }
 }
 
 // ilqr.py:187-231: sequential first-accept over the alphas, evaluated from the precomputed returns.
@@ -252,7 +270,7 @@ int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_optio
     const int T = ws->nb_steps;
     rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->K, ws->kff, ws->xref, ws->uref,
                         ws->weighting, opt->alphas, opt->nb_alphas, nullptr, ws->cand_state, ws->cand_action, nullptr,
-                        ws->cand_ret, ws->cand_finite, st, ws->gains_layout);
+                        ws->cand_ret, ws->cand_finite, st, ws->gains_layout, 0, opt->nb_alphas, nullptr, nullptr);
     if (rc != TRAJOPT_OK) return rc;
     DrvArgs a{*opt, *ws, env->dm_state, env->dm_act};
     const unsigned g1 = (unsigned)((NP + 255) / 256);
@@ -285,6 +303,11 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
     io.g_norm = ws->g_norm; io.active = ws->active;
     io.uref = gminor ? ws->uref : nullptr;  // fused gradient norm needs kff and uref in one layout
     const bool fuse_commit = !opt->keep_value;
+    // staged line search: worth its second 500-step latency chain only once the one-launch form oversubscribes the
+    // chip (1024 SIMDs x 64 lanes); never with argmin (needs every alpha) or a single alpha
+    bool staged = opt->staged_line_search == 1 ||
+                  (opt->staged_line_search < 0 && (int64_t)NP * opt->nb_alphas >= 4 * 65536);
+    if (opt->argmin_alpha || opt->nb_alphas < 2 || !ws->pending_list || !ws->pending_count) staged = false;
     const QuadCommit cm{ws->sel, ws->cand_state, ws->cand_action, ws->cand_K, ws->cand_kff,
                         ws->xref, ws->uref, ws->K, ws->kff};
     for (int it = 0; it < nb_iter; ++it) {
@@ -306,10 +329,25 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         prof_mark(st, slot, 3);
         hipLaunchKernelGGL(post_backward_kernel, dim3(g1), dim3(256), 0, st, a);
         prof_mark(st, slot, 4);
-        rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
-                            ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
-                            ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL);
-        if (rc != TRAJOPT_OK) return rc;
+        if (!staged) {
+            rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
+                                ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
+                                ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 0, opt->nb_alphas,
+                                nullptr, nullptr);
+            if (rc != TRAJOPT_OK) return rc;
+        } else {
+            rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
+                                ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
+                                ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 0, 1, nullptr, nullptr);
+            if (rc != TRAJOPT_OK) return rc;
+            TRAJOPT_HIP_CHECK(hipMemsetAsync(ws->pending_count, 0, sizeof(int32_t), st));
+            hipLaunchKernelGGL(pending_kernel, dim3(g1), dim3(256), 0, st, a);
+            rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
+                                ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
+                                ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 1, opt->nb_alphas,
+                                ws->pending_list, ws->pending_count);
+            if (rc != TRAJOPT_OK) return rc;
+        }
         prof_mark(st, slot, 5);
         hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a);
         if (!fuse_commit || it == nb_iter - 1) {

@@ -21,6 +21,11 @@ struct RolloutArgs {
     double alphas[TRAJOPT_MAX_ALPHAS];
     size_t NP;
     int T, nb_alphas;
+    // optional restriction (staged line search of the driver): alphas [alpha_begin, nb_alphas) only, and, when
+    // plist is given, only the *pcount problems listed there (compacted, so that waves stay full)
+    int alpha_begin;
+    const int32_t* plist;
+    const int32_t* pcount;
 };
 
 template <bool MINOR>
@@ -35,9 +40,18 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     constexpr int N = SYS::N, M = SYS::M;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t NP = a.NP;
-    if (idx >= NP * (size_t)a.nb_alphas) return;
-    const size_t p = idx % NP;
-    const int ai = (int)(idx / NP);
+    size_t p;
+    int ai;
+    if (a.plist) {
+        const size_t cnt = (size_t)*a.pcount;
+        if (idx >= cnt * (size_t)(a.nb_alphas - a.alpha_begin)) return;
+        p = (size_t)a.plist[idx % cnt];
+        ai = a.alpha_begin + (int)(idx / cnt);
+    } else {
+        if (idx >= NP * (size_t)(a.nb_alphas - a.alpha_begin)) return;
+        p = idx % NP;
+        ai = a.alpha_begin + (int)(idx / NP);
+    }
     if (a.active && a.active[p] == 0) return;
     const trajopt_env_t& e = a.env;
     const int n = SYS::n(e), m = SYS::m(e), T = a.T;
@@ -157,7 +171,7 @@ struct RolloutLaunch {
     hipStream_t st;
     template <class SYS>
     void operator()() {
-        const size_t total = a.NP * (size_t)a.nb_alphas;
+        const size_t total = a.NP * (size_t)(a.nb_alphas - a.alpha_begin);
         const dim3 grid((unsigned)((total + 63) / 64)), block(64);
         const bool mi = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR, kmi = k_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
         if (mi && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true>), grid, block, 0, st, a);
@@ -182,8 +196,12 @@ struct StepLaunch {
 int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, const double* x0, const double* K,
                    const double* kff, const double* xref, const double* uref, const double* weighting,
                    const double* alphas_host, int nb_alphas, const int32_t* active, double* state, double* action,
-                   double* cost, double* ret, int32_t* finite, hipStream_t st, int k_layout) {
+                   double* cost, double* ret, int32_t* finite, hipStream_t st, int k_layout, int alpha_begin,
+                   int alpha_end, const int32_t* plist, const int32_t* pcount) {
+    if (alpha_begin < 0 || alpha_end > nb_alphas || alpha_begin >= alpha_end) return TRAJOPT_ERR_BAD_ARG;
     RolloutLaunch L;
+    L.a.alpha_begin = alpha_begin; L.a.plist = plist; L.a.pcount = pcount;
+    nb_alphas = alpha_end;  // the kernel runs alphas [alpha_begin, alpha_end)
     L.a.env = *env;
     L.a.x0 = x0; L.a.K = K; L.a.kff = kff; L.a.xref = xref; L.a.uref = uref; L.a.weighting = weighting;
     L.a.active = active; L.a.state = state; L.a.action = action; L.a.cost = cost; L.a.ret = ret; L.a.finite = finite;
@@ -210,7 +228,8 @@ int trajopt_ilqr_forward_pass_batched(const trajopt_env_t* env, int nb_steps, in
     if (nb_steps <= 0 || nb_problems <= 0 || nb_alphas <= 0 || nb_alphas > TRAJOPT_MAX_ALPHAS) return TRAJOPT_ERR_BAD_ARG;
     if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
     return launch_rollout(env, nb_steps, nb_problems, layout, x0, K, kff, xref, uref, weighting, alphas_host, nb_alphas,
-                          active, state, action, cost, ret, finite, as_stream(stream), layout);
+                          active, state, action, cost, ret, finite, as_stream(stream), layout, 0, nb_alphas, nullptr,
+                          nullptr);
 }
 
 int trajopt_env_step_batched(const trajopt_env_t* env, const double* x, const double* u, const double* u_last,

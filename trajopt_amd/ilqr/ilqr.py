@@ -57,7 +57,8 @@ class BatchedILQR:
     def __init__(self, env, nb_steps, init_state, kff_init=None, activation=None, slew_rate=False,
                  action_penalty=False, alphas=DEFAULT_ALPHAS, lmbda=1., dlmbda=1., min_lmbda=1e-6, max_lmbda=1e6,
                  mult_lmbda=1.6, tolfun=1e-6, tolgrad=1e-4, min_imp=0., reg=1, argmin_alpha=False,
-                 keep_value=False, trace_cap=None, device=None, apply_env_kwargs=True, gains_layout=None):
+                 keep_value=False, trace_cap=None, device=None, apply_env_kwargs=True, gains_layout=None,
+                 staged_line_search=-1):
         import torch
         _lib.require_gpu()
         self.env = env
@@ -117,6 +118,7 @@ class BatchedILQR:
         self._diverge, self._active, self._sel = torch.zeros(N, **i32), torch.zeros(N, **i32), torch.zeros(N, **i32)
         self._cand_state, self._cand_action = z(na, T + 1, n, N), z(na, T, m, N)
         self._cand_ret, self._cand_finite = z(na, N), torch.zeros((na, N), **i32)
+        self._pending_list, self._pending_count = torch.zeros(N, **i32), torch.zeros(1, **i32)
         if self.keep_value:
             self.V, self.v = zg(n, n, T + 1), zg(n, T + 1)
             self.Qxx, self.Qux, self.Quu = zg(n, n, T), zg(m, n, T), zg(m, m, T)
@@ -132,6 +134,7 @@ class BatchedILQR:
         for i, a in enumerate(self.alphas):
             o.alphas[i] = float(a)
         o.argmin_alpha, o.keep_value = int(bool(argmin_alpha)), int(self.keep_value)
+        o.staged_line_search = int(staged_line_search)  # -1 auto, 0 one launch, 1 staged (same results)
         self._opt = o
         self._ws = self._make_ws()
         self._initialised = False
@@ -178,7 +181,7 @@ class BatchedILQR:
         for k in pub:
             setattr(w, k, dptr(getattr(self, k)))
         for k in ("A", "B", "Cxx", "cx", "Cuu", "cu", "Cxu", "cand_K", "cand_kff", "dV", "g_norm", "diverge", "active",
-                  "sel", "cand_state", "cand_action", "cand_ret", "cand_finite"):
+                  "sel", "cand_state", "cand_action", "cand_ret", "cand_finite", "pending_list", "pending_count"):
             setattr(w, k, dptr(getattr(self, "_" + k)))
         if self.keep_value:
             for k in ("V", "v", "Qxx", "Qux", "Quu", "qx", "qu"):
