@@ -50,7 +50,7 @@ def test_ilqr_backward_matches_oracle(oracle, n, m, T, N, layout, reg):
 @pytest.fixture
 def force_kernel():
     """Route the batched entry to one kernel family: 1 workgroup-per-problem, 2 MFMA wave-per-problem,
-    3 lane-per-problem (0 = the library's own choice)."""
+    3 lane-per-problem, 4 MFMA four-problems-per-wave (0 = the library's own choice)."""
     from trajopt_amd._lib import lib
     yield lambda which: lib().trajopt_debug_force_kernel(int(which))
     lib().trajopt_debug_force_kernel(0)
@@ -62,6 +62,8 @@ def force_kernel():
     (2, 12, 4, 40, 6, 0), (2, 12, 4, 40, 6, 1), (2, 8, 2, 25, 4, 0), (2, 13, 3, 12, 3, 0), (2, 15, 1, 12, 3, 1),
     (2, 3, 2, 12, 3, 0), (2, 9, 4, 12, 3, 0), (2, 2, 1, 12, 3, 1),
     (3, 6, 1, 50, 70, 1), (3, 4, 2, 30, 66, 1), (3, 2, 1, 30, 5, 1),                            # lane = problem
+    (4, 4, 1, 64, 130, 1), (4, 4, 1, 40, 1, 0), (4, 3, 1, 33, 21, 1), (4, 2, 1, 100, 3, 1),    # MFMA, 4 problems / wave
+    (4, 4, 1, 500, 37, 1),
 ])
 @pytest.mark.parametrize("reg", [1, 2])
 def test_every_kernel_family_matches_oracle(oracle, force_kernel, kernel, n, m, T, N, layout, reg):
@@ -81,17 +83,17 @@ def test_every_kernel_family_matches_oracle(oracle, force_kernel, kernel, n, m, 
         assert res["g_norm"][p] == pytest.approx(g, rel=1e-9)
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
-def test_asymmetric_cost_hessians_are_taken_as_given(oracle, force_kernel, kernel):
+@pytest.mark.parametrize("kernel,n,m", [(1, 6, 2), (2, 6, 2), (3, 4, 1), (4, 4, 1), (4, 3, 1)])
+def test_asymmetric_cost_hessians_are_taken_as_given(oracle, force_kernel, kernel, n, m):
     """util.cpp uses Cxx as passed (no symmetry assumed); only V is symmetrised (:161)."""
     from trajopt_amd import synthetic as S
-    n, m, T, N = 6, 2, 10, 3
+    T, N = 10, 3
     force_kernel(kernel)
     stack = S.backward_inputs(n, m, T, N, seed=99)
     Cxx = np.array(stack["Cxx"])
     Cxx[:, 0, 1, :] += 0.05          # asymmetric, terminal slice included
     stack = dict(stack, Cxx=Cxx)
-    res = _run_gpu(stack, 1.0, 1, n, m, T, N, 0)
+    res = _run_gpu(stack, 1.0, 1, n, m, T, N, 1 if kernel >= 3 else 0)
     for p in range(N):
         q = S.problem(stack, p)
         ref, _ = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], 1.0, 1, n, m, T)

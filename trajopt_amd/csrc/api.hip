@@ -16,7 +16,8 @@ void set_hip_error(hipError_t e, const char* where) {
 
 extern int g_tpp_dbg_same_step;
 extern int g_tpp_lpw;
-static int g_force_kernel = 0;  // tests / benches: 0 auto, 1 workgroup-per-problem, 2 MFMA wave-per-problem, 3 lane-per-problem
+// tests / benches: 0 auto, 1 workgroup-per-problem, 2 MFMA wave-per-problem, 3 lane-per-problem, 4 MFMA 4 problems per wave
+static int g_force_kernel = 0;
 
 template <bool TO_MINOR>
 __global__ void convert_layout_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t E, size_t NP) {
@@ -40,6 +41,12 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t count) { n = count; return hipMalloc(&p, (count ? count : 1) * sizeof(double)); }
 };
+
+// Above this batch size the lane-per-problem kernel (full waves, every access a whole 512-byte row) wins over the
+// four-problems-per-wave matrix-core kernel (shortest dependent chain per step, but a wave uses only 32 bytes of each
+// 128-byte line it touches, so it saturates the texture addressers at ~5.4 G problem-steps/s).  Measured crossover
+// on MI355X, dx = 4: 0.37 vs 0.57 ms at 4096 problems, 0.76 vs 0.60 ms at 8192.
+constexpr int64_t kMfma4MaxProblems = 6144;
 
 static bool tpp_offsets_fit(int n, int64_t NP) { return (double)n * n * (double)NP * 8.0 + 512.0 < 4294967296.0; }
 
@@ -99,7 +106,13 @@ int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg,
     // Kernel choice:  lane = problem for the struct-of-arrays layout and dx <= 6 (NP == 1: the two layouts are the
     // same memory)  ->  wave = problem on the fp64 matrix cores (dx + du <= 16, du <= 4; best with PROBLEM_MAJOR,
     // whose per-step slices are contiguous)  ->  workgroup = problem.
-    const bool tpp_ok = (layout == TRAJOPT_LAYOUT_PROBLEM_MINOR || NP == 1) && tpp_offsets_fit(n, NP);
+    const bool minor = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR || NP == 1;
+    if (minor && (g_force_kernel == 4 || (g_force_kernel == 0 && NP <= kMfma4MaxProblems))) {
+        bool handled = false;
+        const int rc = launch_backward_mfma4(*io, reg, n, m, T, NP, retry, s, st, &handled);
+        if (rc != TRAJOPT_OK || handled) return rc;
+    }
+    const bool tpp_ok = minor && tpp_offsets_fit(n, NP);
     if (tpp_ok && (g_force_kernel == 3 || g_force_kernel == 0)) {
         bool handled = false;
         const int rc = launch_backward_tpp(*io, reg, n, m, T, NP, retry, s, st, &handled);

@@ -33,6 +33,8 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // Kernel launchers implemented per translation unit (all return TRAJOPT_* codes).
 int launch_backward_tpp(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int retry,
                         const trajopt_lambda_schedule_t& sched, hipStream_t st, bool* handled);
+int launch_backward_mfma4(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int retry,
+                          const trajopt_lambda_schedule_t& sched, hipStream_t st, bool* handled);
 int launch_backward_mfma16(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int layout,
                            int retry, const trajopt_lambda_schedule_t& sched, hipStream_t st, bool* handled);
 int launch_backward_wg(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int layout,
