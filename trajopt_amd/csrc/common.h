@@ -28,6 +28,15 @@ __host__ __device__ inline size_t elem_off(size_t e, size_t p, size_t NP, size_t
 constexpr double kEps = 2.220446049250313e-16;
 constexpr int kMaxLambdaRetries = 128;  // lambda grows super-exponentially: 1e-6 -> 1e300 takes < 70 retries
 
+// 1 / x to ~1 ulp from the hardware estimate and two Newton steps: ~45 cycles instead of the ~80 of an IEEE
+// division (no scaling / fix-up: x must be a normal, finite, non-zero number - here always a positive pivot).
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Kernel launchers implemented per translation unit (all return TRAJOPT_* codes).

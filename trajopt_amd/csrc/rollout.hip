@@ -8,6 +8,7 @@
 // problems fastest, so in PROBLEM_MINOR layout every load of K/kff/xref/uref and every store of the
 // candidate state/action/cost is one coalesced row per wave, and the alphas of a problem re-read the
 // same gain rows from L2.  The inputs of step t+1 are fetched while step t integrates.
+#include <cstddef>
 #include "sys.h"
 
 namespace trajopt {
@@ -42,18 +43,45 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     const size_t NP = a.NP;
     size_t p;
     int ai;
+    bool idle = false;  // no early return before the barrier below
     if (a.plist) {
         const size_t cnt = (size_t)*a.pcount;
-        if (idx >= cnt * (size_t)(a.nb_alphas - a.alpha_begin)) return;
-        p = (size_t)a.plist[idx % cnt];
-        ai = a.alpha_begin + (int)(idx / cnt);
+        idle = idx >= cnt * (size_t)(a.nb_alphas - a.alpha_begin);
+        p = idle ? 0 : (size_t)a.plist[idx % (cnt ? cnt : 1)];
+        ai = idle ? a.alpha_begin : a.alpha_begin + (int)(idx / (cnt ? cnt : 1));
     } else {
-        if (idx >= NP * (size_t)(a.nb_alphas - a.alpha_begin)) return;
-        p = idx % NP;
-        ai = a.alpha_begin + (int)(idx / NP);
+        idle = idx >= NP * (size_t)(a.nb_alphas - a.alpha_begin);
+        p = idle ? 0 : idx % NP;
+        ai = idle ? a.alpha_begin : a.alpha_begin + (int)(idx / NP);
     }
-    if (a.active && a.active[p] == 0) return;
-    const trajopt_env_t& e = a.env;
+    // The env constants (dt, limits, weights, physical parameters: ~30 doubles for a cartpole) plus the sincos
+    // coefficients do not fit the scalar register file: left in the kernel-argument segment they are spilled and
+    // re-read (s_load + wait, v_readlane) inside the time loop, which a lone wave pays for in full.  A copy read
+    // back from LDS lives in VGPRs (plentiful here); only the fields a model uses survive as registers.  The LQR
+    // env indexes its matrices with run-time dimensions and keeps the kernel-argument copy.
+    __shared__ trajopt_env_t s_env;
+    if constexpr (SYS::kStatic) {
+        // everything but the LQR matrices: [0, lin_A) and [phys, end) - 64 doubles, one pass of the wave
+        constexpr unsigned kHead = offsetof(trajopt_env_t, lin_A) / sizeof(double);
+        constexpr unsigned kPhys = offsetof(trajopt_env_t, phys) / sizeof(double);
+        constexpr unsigned kEnd = sizeof(trajopt_env_t) / sizeof(double);
+        double* dst = reinterpret_cast<double*>(&s_env);
+        const double* src = reinterpret_cast<const double*>(&a.env);
+        for (unsigned i = threadIdx.x; i < kHead + (kEnd - kPhys); i += blockDim.x) {
+            const unsigned j = i < kHead ? i : kPhys + (i - kHead);
+            dst[j] = src[j];
+        }
+        __syncthreads();
+    }
+    if (idle || (a.active && a.active[p] == 0)) return;
+    trajopt_env_t ev;
+    if constexpr (SYS::kStatic) {
+        ev = s_env;
+        ev.slew_rate = a.env.slew_rate;  // flags stay wave-uniform so that their branches stay scalar
+        ev.periodic = a.env.periodic;
+        ev.cost_times_dt = a.env.cost_times_dt;
+    }
+    const trajopt_env_t& e = SYS::kStatic ? ev : a.env;
     const int n = SYS::n(e), m = SYS::m(e), T = a.T;
     const double alpha = a.alphas[ai];
     const size_t En1 = (size_t)n * (T + 1), En = (size_t)n * T, Em = (size_t)m * T, Enm = (size_t)n * m * T;
@@ -70,7 +98,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         if (i < n) {
             x[i] = a.x0[gi<MINOR>(i, n, p, NP)];
             fin = fin && (x[i] < 1e8);
-            if (st) st[gi<MINOR>(i, En1, p, NP)] = x[i];
+            if (a.state) st[gi<MINOR>(i, En1, p, NP)] = x[i];
         }
     auto load = [&](int t) {
 #pragma unroll
@@ -106,8 +134,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         w = a.weighting[t + 1];
         const double c = env_cost<N, M>(e, x, u, u, wt, n, m);  // ilqr.py:98 passes u_last = u_t
         total += c;
-        if (co) co[gi<MINOR>(t, T + 1, p, NP)] = c;
-        if (ac) {
+        if (a.cost) co[gi<MINOR>(t, T + 1, p, NP)] = c;
+        if (a.action) {
 #pragma unroll
             for (int j = 0; j < M; ++j)
                 if (j < m) ac[gi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
@@ -119,7 +147,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
             if (i < n) {
                 x[i] = xn[i];
                 fin = fin && (x[i] < 1e8);
-                if (st) st[gi<MINOR>((size_t)n * (t + 1) + i, En1, p, NP)] = x[i];
+                if (a.state) st[gi<MINOR>((size_t)n * (t + 1) + i, En1, p, NP)] = x[i];
             }
     }
     {
@@ -128,7 +156,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         for (int j = 0; j < M; ++j) zero[j] = 0.0;
         const double c = env_cost<N, M>(e, x, zero, zero, w, n, m);  // ilqr.py:101
         total += c;
-        if (co) co[gi<MINOR>(T, T + 1, p, NP)] = c;
+        if (a.cost) co[gi<MINOR>(T, T + 1, p, NP)] = c;
     }
     if (a.ret) a.ret[(size_t)ai * NP + p] = total;
     if (a.finite) a.finite[(size_t)ai * NP + p] = fin ? 1 : 0;

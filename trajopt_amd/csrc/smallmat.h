@@ -107,15 +107,6 @@ __device__ __forceinline__ void chol_solve(const double (&L)[M * M], double (&x)
     }
 }
 
-// 1 / x to ~1 ulp from the hardware estimate and two Newton steps: ~45 cycles instead of the ~80 of an IEEE
-// division (no scaling / fix-up: x must be a normal, finite, non-zero number - here always a positive pivot).
-__device__ __forceinline__ double rcp_nr(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(r, fma(-x, r, 1.0), r);
-    r = fma(r, fma(-x, r, 1.0), r);
-    return r;
-}
-
 // Same PD rule as sympd_factor() (Armadillo's is_sympd, util.cpp:145) but square-root-free and with every
 // division turned into one refined reciprocal per pivot: X = L D L' with unit lower L and id[j] = 1 / D[j].
 // The test factorises X - tol I (pivots must be > 0), the returned factors are those of X itself.
