@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TRAJOPT_ABI_VERSION 1
+#define TRAJOPT_ABI_VERSION 2
 
 #define TRAJOPT_OK 0
 #define TRAJOPT_ERR_BAD_ARG (-1)      /* null pointer, non-positive size, unknown enum            */
@@ -100,7 +100,20 @@ typedef struct trajopt_backward_io {
     double* g_norm;       /* [nb_problems], may be NULL */
     /* optional activity mask [nb_problems]: problems with active[p] == 0 are skipped entirely */
     const int32_t* active;
+    /* Optional structured cost.  Every env of the hot path has identity features, so its cost Hessians are
+     * closed-form (ilqr/objects.py:74-78 applied to e.g. cartpole.py:112-127): Cxx[t] = w[t] diag(gxx),
+     * Cuu[t] = diag(guu), Cxu = 0, the same for every problem.  With cost_w non-NULL the kernels take them from
+     * here - w is the [nb_steps+1] weighting vector shared by all problems, gxx = 2 gw (times dt for the LQR
+     * envs), guu = 2 uw - and the dense Cxx, Cuu, Cxu pointers above are ignored (may be NULL): 21 of the 51
+     * doubles a cartpole step reads.  Supported for PROBLEM_MINOR, dm_state <= 6 (see
+     * trajopt_backward_supports_structured_cost); other shapes return TRAJOPT_ERR_UNSUPPORTED. */
+    const double* cost_w;
+    double cost_gxx[TRAJOPT_ENV_MAX_STATE];
+    double cost_guu[TRAJOPT_ENV_MAX_ACT];
 } trajopt_backward_io_t;
+
+/* 1 when the batched backward pass accepts io->cost_w for this shape, else 0. */
+int trajopt_backward_supports_structured_cost(int dm_state, int dm_act, int nb_steps, int64_t nb_problems, int layout);
 
 /* Batched backward pass on device arrays.  reg: 1 = lmbda*I on Quu, 2 = lmbda*I on V' (util.cpp:135-143),
  * anything else = no regularisation term (as the reference).  retry != 0 repeats a diverged problem

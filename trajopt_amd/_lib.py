@@ -45,10 +45,11 @@ _dp = C.c_void_p  # device pointers travel as integers
 
 class BackwardIO(C.Structure):
     """include/trajopt_amd.h::trajopt_backward_io_t"""
-    _fields_ = [(k, _dp) for k in
-                ("Cxx", "cx", "Cuu", "cu", "Cxu", "A", "B", "lmbda", "dlmbda",
-                 "Qxx", "Qux", "Quu", "qx", "qu", "V", "v", "dV", "K", "kff", "diverge",
-                 "uref", "g_norm", "active")]
+    _fields_ = ([(k, _dp) for k in
+                 ("Cxx", "cx", "Cuu", "cu", "Cxu", "A", "B", "lmbda", "dlmbda",
+                  "Qxx", "Qux", "Quu", "qx", "qu", "V", "v", "dV", "K", "kff", "diverge",
+                  "uref", "g_norm", "active", "cost_w")] +
+                [("cost_gxx", C.c_double * MAX_STATE), ("cost_guu", C.c_double * MAX_ACT)])
 
 
 class ILQROptions(C.Structure):
@@ -74,6 +75,7 @@ class ILQRWorkspace(C.Structure):
 EXPORTS = (
     "trajopt_abi_version", "trajopt_error_string", "trajopt_last_hip_error", "trajopt_device_count",
     "trajopt_ilqr_backward_pass_host", "trajopt_ilqr_backward_pass_batched",
+    "trajopt_backward_supports_structured_cost",
     "trajopt_riccati_backward_pass_host", "trajopt_riccati_backward_pass_batched",
     "trajopt_env_step_batched", "trajopt_ilqr_forward_pass_batched", "trajopt_quadratize_batched",
     "trajopt_ilqr_init_rollout", "trajopt_ilqr_iterate", "trajopt_convert_layout",

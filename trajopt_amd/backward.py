@@ -16,22 +16,25 @@ def _chk(t, numel, name):
 
 
 def ilqr_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, dm_state, dm_act, nb_steps, nb_problems, layout,
-                       full=True, retry=False, sched=None, dlmbda=None, uref=None, active=None, out=None):
+                       full=True, retry=False, sched=None, dlmbda=None, uref=None, active=None, out=None, cost=None):
     """Regularised Riccati recursion of /root/reference/trajopt/ilqr/src/util.cpp:83-182 for a batch.
 
     Inputs are device tensors in `layout` (see layout.py); `lmbda` is a [N] tensor (updated in place when
     retry=True).  Returns a dict with K, kff, dV, diverge (and Qxx, Qux, Quu, qx, qu, V, v when full=True,
     g_norm when uref is given).  diverge[p] = -1 when every step passed the PD test.
+    cost=(w, gxx, guu): structured cost (trajopt_backward_io_t::cost_w) - Cxx[t] = w[t] diag(gxx), Cuu = diag(guu),
+    Cxu = 0 for every problem, w a [T+1] device tensor; Cxx, Cuu, Cxu are then ignored and may be None.
     """
     import torch
     _lib.require_gpu()
     n, m, T, N = dm_state, dm_act, nb_steps, nb_problems
-    for t, cnt, nm in ((Cxx, n * n * (T + 1), "Cxx"), (cx, n * (T + 1), "cx"), (Cuu, m * m * (T + 1), "Cuu"),
-                       (cu, m * (T + 1), "cu"), (Cxu, n * m * (T + 1), "Cxu"), (A, n * n * T, "A"),
-                       (B, n * m * T, "B")):
+    dense = () if cost is not None else ((Cxx, n * n * (T + 1), "Cxx"), (Cuu, m * m * (T + 1), "Cuu"),
+                                         (Cxu, n * m * (T + 1), "Cxu"))
+    for t, cnt, nm in dense + ((cx, n * (T + 1), "cx"), (cu, m * (T + 1), "cu"), (A, n * n * T, "A"),
+                               (B, n * m * T, "B")):
         _chk(t, cnt * N, nm)
     _chk(lmbda, N, "lmbda")
-    dev = Cxx.device
+    dev = A.device
     o = {} if out is None else out
     o.setdefault("K", empty((N, m, n, T), layout, dev, zero=True))
     o.setdefault("kff", empty((N, m, T), layout, dev, zero=True))
@@ -49,7 +52,18 @@ def ilqr_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, dm_state, dm_act
     if uref is not None and "g_norm" not in o:
         o["g_norm"] = torch.empty(N, dtype=torch.float64, device=dev)
     io = BackwardIO()
-    io.Cxx, io.cx, io.Cuu, io.cu, io.Cxu, io.A, io.B = map(dptr, (Cxx, cx, Cuu, cu, Cxu, A, B))
+    io.cx, io.cu, io.A, io.B = map(dptr, (cx, cu, A, B))
+    if cost is None:
+        io.Cxx, io.Cuu, io.Cxu = map(dptr, (Cxx, Cuu, Cxu))
+    else:
+        w, gxx, guu = cost
+        if w.dtype != torch.float64 or not w.is_cuda or not w.is_contiguous() or w.numel() != T + 1:
+            raise ValueError("cost weighting must be a contiguous CUDA float64 tensor with %d elements" % (T + 1))
+        io.cost_w = dptr(w)
+        for i in range(n):
+            io.cost_gxx[i] = float(gxx[i])
+        for j in range(m):
+            io.cost_guu[j] = float(guu[j])
     io.lmbda, io.dlmbda = dptr(lmbda), dptr(dlmbda)
     for k in ("Qxx", "Qux", "Quu", "qx", "qu", "V", "v"):
         setattr(io, k, dptr(o.get(k)) if full else None)

@@ -92,14 +92,22 @@ int trajopt_debug_tpp_same_step(int on) {
     return TRAJOPT_OK;
 }
 
+int trajopt_backward_supports_structured_cost(int n, int m, int T, int64_t NP, int layout) {
+    // exactly the shapes the lane-per-problem and the four-problems-per-wave kernels take (see the dispatcher below)
+    if (n <= 0 || m <= 0 || T <= 0 || NP <= 0) return 0;
+    if (!(layout == TRAJOPT_LAYOUT_PROBLEM_MINOR || NP == 1) || !tpp_offsets_fit(n, NP)) return 0;
+    return ((m == 1 && (n == 2 || n == 3 || n == 4 || n == 6)) || (n == 4 && m == 2)) ? 1 : 0;
+}
+
 int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg, int n, int m, int T, int64_t NP,
                                        int layout, int retry, const trajopt_lambda_schedule_t* sched,
                                        void* stream) {
     if (!io || n <= 0 || m <= 0 || T <= 0 || NP <= 0) return TRAJOPT_ERR_BAD_ARG;
     if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
-    if (!io->Cxx || !io->cx || !io->Cuu || !io->cu || !io->Cxu || !io->A || !io->B || !io->lmbda || !io->dV ||
-        !io->K || !io->kff || !io->diverge)
+    if (!io->cx || !io->cu || !io->A || !io->B || !io->lmbda || !io->dV || !io->K || !io->kff || !io->diverge)
         return TRAJOPT_ERR_BAD_ARG;
+    if (!io->cost_w && (!io->Cxx || !io->Cuu || !io->Cxu)) return TRAJOPT_ERR_BAD_ARG;
+    if (io->cost_w && !trajopt_backward_supports_structured_cost(n, m, T, NP, layout)) return TRAJOPT_ERR_UNSUPPORTED;
     if (retry && !sched) return TRAJOPT_ERR_BAD_ARG;
     trajopt_lambda_schedule_t s = sched ? *sched : trajopt_lambda_schedule_t{1e-6, 1e6, 1.6};
     hipStream_t st = as_stream(stream);
@@ -118,6 +126,7 @@ int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg,
         const int rc = launch_backward_tpp(*io, reg, n, m, T, NP, retry, s, st, &handled);
         if (rc != TRAJOPT_OK || handled) return rc;
     }
+    if (io->cost_w) return TRAJOPT_ERR_UNSUPPORTED;  // (a forced kernel family without the structured-cost path)
     if (g_force_kernel == 0 || g_force_kernel == 2) {
         bool handled = false;
         const int rc = launch_backward_mfma16(*io, reg, n, m, T, NP, layout, retry, s, st, &handled);

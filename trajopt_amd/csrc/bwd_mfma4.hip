@@ -60,6 +60,7 @@ __device__ __forceinline__ void m4_st(double x, double* base, unsigned off) {
 
 struct M4In {  // one step's inputs, each already in the lane layout of the operand it feeds
     double A, BR, Cxx, CxuR, cxR, CuuF, cuF, urF;
+    double wF;      // structured cost only: the weighting w[t], in place of Cxx, CxuR, CuuF
 };
 constexpr int kRing = 7;  // prefetch distance in steps
 
@@ -68,26 +69,33 @@ struct M4Off {
     unsigned rc, r, c, z;
 };
 
-template <int N, bool GN>
-__device__ __forceinline__ void m4_load(M4In& s, const trajopt_backward_io_t& io, const M4Off& o, bool in_rc, bool in_r) {
+// SC: structured cost (trajopt_backward_io_t::cost_w) - Cxx = w[t] diag(gxx), Cuu = guu, Cxu = 0 are not loaded;
+// `wofs` is the byte offset of w[t] (the same for every lane: one line).
+template <int N, bool GN, bool SC>
+__device__ __forceinline__ void m4_load(M4In& s, const trajopt_backward_io_t& io, const M4Off& o, unsigned wofs,
+                                        bool in_rc, bool in_r) {
     s.A = m4_ld(io.A, o.rc);
     s.BR = m4_ld(io.B, o.r);
-    s.Cxx = m4_ld(io.Cxx, o.rc);
-    s.CxuR = m4_ld(io.Cxu, o.r);
+    if constexpr (SC) {
+        s.wF = m4_ld(io.cost_w, wofs);
+    } else {
+        s.Cxx = m4_ld(io.Cxx, o.rc);
+        s.CxuR = m4_ld(io.Cxu, o.r);
+        s.CuuF = m4_ld(io.Cuu, o.z);
+    }
     s.cxR = m4_ld(io.cx, o.r);
-    s.CuuF = m4_ld(io.Cuu, o.z);
     s.cuF = m4_ld(io.cu, o.z);
     if constexpr (GN) s.urF = m4_ld(io.uref, o.z);
     if constexpr (N < 4) {  // padding lanes of a smaller state: zero rows / columns
-        if (!in_rc) { s.A = 0.0; s.Cxx = 0.0; }
-        if (!in_r) { s.BR = 0.0; s.CxuR = 0.0; s.cxR = 0.0; }
+        if (!in_rc) { s.A = 0.0; if constexpr (!SC) s.Cxx = 0.0; }
+        if (!in_r) { s.BR = 0.0; s.cxR = 0.0; if constexpr (!SC) s.CxuR = 0.0; }
     }
 }
 
 // REG: 1 / 2 = the reference's regularisation modes (util.cpp:135-143), 0 = none (any other value of `reg`).
 // __launch_bounds__(256, 2): at most 256 VGPRs, which lets hipcc keep the MFMA results in VGPRs instead of AGPRs
 // (no v_accvgpr_read/write around every matrix-core instruction).
-template <int N, int REG, bool FULL, bool GN>
+template <int N, int REG, bool FULL, bool GN, bool SC>
 __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned r = lane >> 4, q = (lane >> 2) & 3u, c = lane & 3u;
@@ -119,6 +127,9 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
     double dV0 = 0.0, dV1 = 0.0, gmax = -INFINITY;
     bool frozen = skip;  // frozen blocks take part in the wave's arithmetic but keep their results and store nothing
     const double eye = (r == c) ? 1.0 : 0.0;  // identity as a B operand: mfma(X, eye, 0) = X^T
+    // structured cost: Cxx[t] = w[t] dg with dg = diag(gxx) in the C-operand layout, Cuu = guu
+    const double dg = (SC && r == c && in_r) ? io.cost_gxx[r] : 0.0;
+    const double guu = SC ? io.cost_guu[0] : 0.0;
 
     for (;;) {
         bool alive = !frozen;
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
         double VT, vR;
         {
             const M4Off oT = slice(T);
-            double VTerm = m4_ld(io.Cxx, oT.rc);
+            double VTerm = SC ? m4_ld(io.cost_w, (unsigned)T * 8u) * dg : m4_ld(io.Cxx, oT.rc);
             vR = m4_ld(io.cx, oT.r);
             if constexpr (N < 4) {
                 if (!in_rc) VTerm = 0.0;
@@ -144,13 +155,14 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
             VT = m4_mm(VTerm, eye, 0.0);
         }
         M4Off ol = slice(T - 1), os = ol;  // slice being loaded / slice being computed and stored
+        unsigned wl = (unsigned)(T - 1) * 8u;  // byte offset of w[slice being loaded]
         M4In ring[kRing];
 #pragma unroll
         for (int k = 0; k < kRing; ++k) {
             // unconditional (a load under a branch makes the waitcnt pass drain the queue at the loop header): a
             // horizon shorter than the ring re-loads slice 0 into the slots it never uses
-            m4_load<N, GN>(ring[k], io, ol, in_rc, in_r);
-            if (T - 2 - k >= 0) back(ol);
+            m4_load<N, GN, SC>(ring[k], io, ol, wl, in_rc, in_r);
+            if (T - 2 - k >= 0) { back(ol); wl -= 8u; }
             // keep the prologue's loads in slot order, the order the loop refills them in: the waitcnt pass merges
             // both at the loop header and otherwise drains every load (vmcnt(0)) once per trip round the ring
             __builtin_amdgcn_sched_barrier(0);
@@ -161,9 +173,9 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
             const double P0 = m4_mm(VT, in.A, 0.0);
             const double quF = m4_mm(in.BR, vR, in.cuF);
             const double qxR = m4_mm(in.A, vR, in.cxR);
-            const double QuuF = m4_mm(in.BR, ZR, in.CuuF);
-            const double QxuR = m4_mm(in.A, ZR, in.CxuR);
-            const double Qxx = m4_mm(in.A, P0, in.Cxx);
+            const double QuuF = m4_mm(in.BR, ZR, SC ? guu : in.CuuF);
+            const double QxuR = m4_mm(in.A, ZR, SC ? 0.0 : in.CxuR);
+            const double Qxx = m4_mm(in.A, P0, SC ? in.wF * dg : in.Cxx);
             const double QxuC = m4_mm(QxuR, eye, 0.0);  // D[i][j] = Qxu[j]
             const double Qs = m4_mm(Qxx, eye, Qxx);     // Qxx + Qxx' (one rounding per entry: bitwise symmetric)
             // regularisation (util.cpp:135-143)
@@ -240,8 +252,8 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
 #pragma unroll
             for (int k = 0; k < kRing; ++k) {
                 step(ring[k], t);
-                m4_load<N, GN>(ring[k], io, ol, in_rc, in_r);
-                if (!a.dbg_same_step) back(ol);
+                m4_load<N, GN, SC>(ring[k], io, ol, wl, in_rc, in_r);
+                if (!a.dbg_same_step) { back(ol); wl -= 8u; }
                 --t;
             }
         }
@@ -250,8 +262,9 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
             if (t >= 0) {
                 step(ring[k % kRing], t);
                 if (k < kRing - 1 && t - kRing >= 0) {
-                    m4_load<N, GN>(ring[k % kRing], io, ol, in_rc, in_r);
+                    m4_load<N, GN, SC>(ring[k % kRing], io, ol, wl, in_rc, in_r);
                     back(ol);
+                    wl -= 8u;
                 }
                 --t;
             }
@@ -289,20 +302,24 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
     }
 }
 
-template <int N, int REG>
-static int m4_launch_nr(const M4Args& a, hipStream_t st) {
+template <int N, int REG, bool SC>
+static int m4_launch_nrs(const M4Args& a, hipStream_t st) {
     const bool full = a.io.Qxx || a.io.Qux || a.io.Quu || a.io.qx || a.io.qu || a.io.V || a.io.v;
     const bool gn = a.io.uref != nullptr && a.io.g_norm != nullptr;
     const dim3 block(256), grid((unsigned)((a.NP + 15) / 16));
     if (full) {
-        if (gn) hipLaunchKernelGGL((bwd_mfma4_kernel<N, REG, true, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((bwd_mfma4_kernel<N, REG, true, false>), grid, block, 0, st, a);
+        if (gn) hipLaunchKernelGGL((bwd_mfma4_kernel<N, REG, true, true, SC>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((bwd_mfma4_kernel<N, REG, true, false, SC>), grid, block, 0, st, a);
     } else {
-        if (gn) hipLaunchKernelGGL((bwd_mfma4_kernel<N, REG, false, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((bwd_mfma4_kernel<N, REG, false, false>), grid, block, 0, st, a);
+        if (gn) hipLaunchKernelGGL((bwd_mfma4_kernel<N, REG, false, true, SC>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((bwd_mfma4_kernel<N, REG, false, false, SC>), grid, block, 0, st, a);
     }
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
+}
+template <int N, int REG>
+static int m4_launch_nr(const M4Args& a, hipStream_t st) {
+    return a.io.cost_w ? m4_launch_nrs<N, REG, true>(a, st) : m4_launch_nrs<N, REG, false>(a, st);
 }
 template <int N>
 static int m4_launch_n(const M4Args& a, hipStream_t st) {

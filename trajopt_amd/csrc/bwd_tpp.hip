@@ -60,15 +60,31 @@ __device__ __forceinline__ void store_vec(double* ubase, const Lane& ln, const d
 // ubase(arr, E, t): wave-uniform pointer to element 0 of step t for the wave's first problem.
 #define UBASE(arr, E, t) ((arr) + ((size_t)(t) * (E)) * NP + p0)
 
-template <int N, int M, bool GN>
+// SC: structured cost (trajopt_backward_io_t::cost_w): Cxx = w[t] diag(gxx), Cuu = diag(guu), Cxu = 0 are formed in
+// registers (the zeros fold away at compile time) instead of being loaded - 21 of a cartpole step's 51 loads.
+template <int N, int M, bool GN, bool SC>
 __device__ __forceinline__ void load_step(StepIn<N, M>& s, const TppArgs& a, size_t p0, const Lane& off, int t) {
     const size_t NP = a.NP;
     if (a.dbg_same_step) t = a.T - 1;
     load_vec<N * N>(s.A, UBASE(a.io.A, N * N, t), off);
     load_vec<N * M>(s.B, UBASE(a.io.B, N * M, t), off);
-    load_vec<N * N>(s.Cxx, UBASE(a.io.Cxx, N * N, t), off);
-    load_vec<M * M>(s.Cuu, UBASE(a.io.Cuu, M * M, t), off);
-    load_vec<N * M>(s.Cxu, UBASE(a.io.Cxu, N * M, t), off);
+    if constexpr (SC) {
+        const double w = a.io.cost_w[t];  // wave-uniform: one scalar load, issued a step ahead like the rest
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int i = 0; i < N; ++i) s.Cxx[i + N * j] = (i == j) ? w * a.io.cost_gxx[i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+#pragma unroll
+            for (int i = 0; i < M; ++i) s.Cuu[i + M * j] = (i == j) ? a.io.cost_guu[i] : 0.0;
+#pragma unroll
+        for (int k = 0; k < N * M; ++k) s.Cxu[k] = 0.0;
+    } else {
+        load_vec<N * N>(s.Cxx, UBASE(a.io.Cxx, N * N, t), off);
+        load_vec<M * M>(s.Cuu, UBASE(a.io.Cuu, M * M, t), off);
+        load_vec<N * M>(s.Cxu, UBASE(a.io.Cxu, N * M, t), off);
+    }
     load_vec<N>(s.cx, UBASE(a.io.cx, N, t), off);
     load_vec<M>(s.cu, UBASE(a.io.cu, M, t), off);
     if constexpr (GN) load_vec<M>(s.ur, UBASE(a.io.uref, M, t), off);
@@ -295,7 +311,7 @@ __device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N *
     return true;
 }
 
-template <int N, int M, bool FULL, bool GN>
+template <int N, int M, bool FULL, bool GN, bool SC>
 __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
     const size_t p0 = (size_t)blockIdx.x * a.lpw;  // wave-uniform: first problem of this wave
     const unsigned lane = threadIdx.x;
@@ -320,7 +336,15 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
         double V[N * N], v[N];
         {
             // terminal condition (util.cpp:123-124)
-            load_vec<N * N>(V, UBASE(a.io.Cxx, N * N, T), off);
+            if constexpr (SC) {
+                const double w = a.io.cost_w[T];
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+#pragma unroll
+                    for (int i = 0; i < N; ++i) V[i + N * j] = (i == j) ? w * a.io.cost_gxx[i] : 0.0;
+            } else {
+                load_vec<N * N>(V, UBASE(a.io.Cxx, N * N, T), off);
+            }
             load_vec<N>(v, UBASE(a.io.cx, N, T), off);
             if constexpr (FULL) {
                 if (a.io.V) store_vec<N * N>(UBASE(a.io.V, N * N, T), off, V);
@@ -332,16 +356,16 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
         // vmcnt there, which waits for the prefetch just issued and exposes the whole HBM latency every step.
         StepIn<N, M> s0, s1;
         int t = T - 1;
-        load_step<N, M, GN>(s0, a, p0, off, t);
+        load_step<N, M, GN, SC>(s0, a, p0, off, t);
         while (t >= 0) {
-            load_step<N, M, GN>(s1, a, p0, off, t >= 1 ? t - 1 : 0);
+            load_step<N, M, GN, SC>(s1, a, p0, off, t >= 1 ? t - 1 : 0);
             if (!bwd_step<N, M, FULL, GN>(s0, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, t)) {
                 div = t;
                 break;
             }
             --t;
             if (t < 0) break;
-            load_step<N, M, GN>(s0, a, p0, off, t >= 1 ? t - 1 : 0);
+            load_step<N, M, GN, SC>(s0, a, p0, off, t >= 1 ? t - 1 : 0);
             if (!bwd_step<N, M, FULL, GN>(s1, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, t)) {
                 div = t;
                 break;
@@ -384,21 +408,25 @@ static int pick_lpw(size_t) {
     return 64;
 }
 
-template <int N, int M>
-static int launch_nm(const TppArgs& a, hipStream_t st) {
+template <int N, int M, bool SC>
+static int launch_nms(const TppArgs& a, hipStream_t st) {
     const bool full = a.io.Qxx || a.io.Qux || a.io.Quu || a.io.qx || a.io.qu || a.io.V || a.io.v;
     const bool gn = a.io.uref != nullptr && a.io.g_norm != nullptr;
     const dim3 block(64);
     const dim3 grid((unsigned)((a.NP + a.lpw - 1) / a.lpw));
     if (full) {
-        if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, false>), grid, block, 0, st, a);
+        if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, true, SC>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, false, SC>), grid, block, 0, st, a);
     } else {
-        if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, false>), grid, block, 0, st, a);
+        if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, true, SC>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, false, SC>), grid, block, 0, st, a);
     }
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
+}
+template <int N, int M>
+static int launch_nm(const TppArgs& a, hipStream_t st) {
+    return a.io.cost_w ? launch_nms<N, M, true>(a, st) : launch_nms<N, M, false>(a, st);
 }
 
 int launch_backward_tpp(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int retry,

@@ -302,6 +302,16 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
     const bool gminor = GL == TRAJOPT_LAYOUT_PROBLEM_MINOR;
     io.g_norm = ws->g_norm; io.active = ws->active;
     io.uref = gminor ? ws->uref : nullptr;  // fused gradient norm needs kff and uref in one layout
+    // Structured cost: every env model has identity features, so Cxx = w[t] 2 diag(gw), Cuu = 2 diag(uw), Cxu = 0
+    // (quadratize.hip); when the backward kernel of this shape can form them itself they are neither written by the
+    // quadratisation nor read back - 168 of the 368 bytes a cartpole step moves through HBM each way.
+    const bool structured = trajopt_backward_supports_structured_cost(n, m, T, NP, GL) != 0;
+    if (structured) {
+        const double sc = env->cost_times_dt ? env->dt : 1.0;
+        io.cost_w = ws->weighting;
+        for (int i = 0; i < n; ++i) io.cost_gxx[i] = sc * 2.0 * env->gw[i];
+        for (int j = 0; j < m; ++j) io.cost_guu[j] = sc * 2.0 * env->uw[j];
+    }
     const bool fuse_commit = !opt->keep_value;
     // staged line search: worth its second 500-step latency chain only once the one-launch form oversubscribes the
     // chip (1024 SIMDs x 64 lanes); never with argmin (needs every alpha) or a single alpha
@@ -319,7 +329,8 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         // quadratisation (it reads every (problem, step) of the trajectory anyway); only the last iteration
         // of the call, and the keep_value mode, use the stand-alone commit kernel.
         rc = launch_quadratize(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 0, ws->xref, ws->uref, ws->weighting,
-                               ws->active, ws->A, ws->B, nullptr, ws->Cxx, ws->cx, ws->Cuu, ws->cu, ws->Cxu, st,
+                               ws->active, ws->A, ws->B, nullptr, structured ? nullptr : ws->Cxx, ws->cx,
+                               structured ? nullptr : ws->Cuu, ws->cu, structured ? nullptr : ws->Cxu, st,
                                (fuse_commit && it > 0) ? &cm : nullptr, GL);
         if (rc != TRAJOPT_OK) return rc;
         prof_mark(st, slot, 2);

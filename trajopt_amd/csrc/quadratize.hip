@@ -79,6 +79,19 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
         ul[j] = (j < m && t >= 1) ? usrc[qi<MINOR>((size_t)m * (t - 1) + j, Em, p, NP)] : 0.0;
     }
     if (commit) {
+        // Every load of the commit is issued before its first store: the arrays are not __restrict__, so a store
+        // followed by a load is kept in program order and each such pair costs one more full memory round trip per
+        // wave (the fused commit doubled the kernel's time that way).
+        double cK[N * M], ckff[M];
+        const size_t Enm_ = (size_t)n * m * T;
+        if (t < T) {
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if (j < m) ckff[j] = a.cand_kff[qi<OMINOR>((size_t)m * t + j, Em, p, NP)];
+#pragma unroll
+            for (int k = 0; k < N * M; ++k)
+                if (k < n * m) cK[k] = a.cand_K[qi<OMINOR>((size_t)n * m * t + k, Enm_, p, NP)];
+        }
 #pragma unroll
         for (int i = 0; i < N; ++i)
             if (i < n) a.c_xref[qi<MINOR>((size_t)n * t + i, En1, p, NP)] = x[i];
@@ -87,13 +100,11 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
             for (int j = 0; j < M; ++j)
                 if (j < m) {
                     a.c_uref[qi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
-                    a.c_kff[qi<OMINOR>((size_t)m * t + j, Em, p, NP)] = a.cand_kff[qi<OMINOR>((size_t)m * t + j, Em, p, NP)];
+                    a.c_kff[qi<OMINOR>((size_t)m * t + j, Em, p, NP)] = ckff[j];
                 }
-            const size_t Enm_ = (size_t)n * m * T;
 #pragma unroll
             for (int k = 0; k < N * M; ++k)
-                if (k < n * m)
-                    a.c_K[qi<OMINOR>((size_t)n * m * t + k, Enm_, p, NP)] = a.cand_K[qi<OMINOR>((size_t)n * m * t + k, Enm_, p, NP)];
+                if (k < n * m) a.c_K[qi<OMINOR>((size_t)n * m * t + k, Enm_, p, NP)] = cK[k];
         }
     }
     if (!live) return;
@@ -128,27 +139,31 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
                 double g = 0.0, h = 0.0;
                 if (w != 0.0) {
                     const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
-                    h = sc * 2.0 * w * e.gw[i];
-                    g = sc * 2.0 * w * e.gw[i] * (y - e.goal[i]);
+                    h = w * (sc * 2.0 * e.gw[i]);  // = w[t] * cost_gxx[i], the structured form the backward pass can take
+                    g = h * (y - e.goal[i]);
                 }
                 a.cx[qi<OMINOR>((size_t)n * t + i, En1, p, NP)] = g;
+                if (a.Cxx) {  // NULL: the backward pass forms Cxx, Cuu, Cxu itself (trajopt_backward_io_t::cost_w)
 #pragma unroll
-                for (int j = 0; j < N; ++j)
-                    if (j < n) a.Cxx[qi<OMINOR>((size_t)n * n * t + j + (size_t)n * i, Enn1, p, NP)] = (i == j) ? h : 0.0;
+                    for (int j = 0; j < N; ++j)
+                        if (j < n) a.Cxx[qi<OMINOR>((size_t)n * n * t + j + (size_t)n * i, Enn1, p, NP)] = (i == j) ? h : 0.0;
 #pragma unroll
-                for (int j = 0; j < M; ++j)
-                    if (j < m) a.Cxu[qi<OMINOR>((size_t)n * m * t + i + (size_t)n * j, Enm1, p, NP)] = 0.0;
+                    for (int j = 0; j < M; ++j)
+                        if (j < m) a.Cxu[qi<OMINOR>((size_t)n * m * t + i + (size_t)n * j, Enm1, p, NP)] = 0.0;
+                }
             }
 #pragma unroll
         for (int j = 0; j < M; ++j)
             if (j < m) {
                 const double d = e.slew_rate ? (u[j] - ul[j]) : u[j];
                 a.cu[qi<OMINOR>((size_t)m * t + j, Em1, p, NP)] = sc * 2.0 * e.uw[j] * d;
+                if (a.Cxx) {
 #pragma unroll
-                for (int k = 0; k < M; ++k)
-                    if (k < m)
-                        a.Cuu[qi<OMINOR>((size_t)m * m * t + k + (size_t)m * j, Emm1, p, NP)] =
-                            (k == j) ? sc * 2.0 * e.uw[j] : 0.0;
+                    for (int k = 0; k < M; ++k)
+                        if (k < m)
+                            a.Cuu[qi<OMINOR>((size_t)m * m * t + k + (size_t)m * j, Emm1, p, NP)] =
+                                (k == j) ? sc * 2.0 * e.uw[j] : 0.0;
+                }
             }
     }
 }
