@@ -36,7 +36,10 @@ __device__ __forceinline__ size_t gi(size_t e_total, size_t E_total, size_t p, s
 
 // MINOR: layout of x0 / xref / uref / candidates;  KMINOR: layout of the gains K, kff (the batched driver keeps
 // them PROBLEM_MAJOR for the matrix-core backward kernel when dx > 6).
-template <class SYS, bool MINOR, bool KMINOR>
+// FAST: the batched driver's call - state and action planes given, no per-step cost plane - with the stores
+// unconditional: a store under a (wave-uniform) `if (pointer)` makes the waitcnt pass wait for EVERY outstanding
+// memory operation (vmcnt(0)) before the prefetched gains are used, i.e. for this step's stores to be acknowledged.
+template <class SYS, bool MINOR, bool KMINOR, bool FAST>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     constexpr int N = SYS::N, M = SYS::M;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         if (i < n) {
             x[i] = a.x0[gi<MINOR>(i, n, p, NP)];
             fin = fin && (x[i] < 1e8);
-            if (a.state) st[gi<MINOR>(i, En1, p, NP)] = x[i];
+            if (FAST || a.state) st[gi<MINOR>(i, En1, p, NP)] = x[i];
         }
     auto load = [&](int t) {
 #pragma unroll
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         w = a.weighting[t + 1];
         const double c = env_cost<N, M>(e, x, u, u, wt, n, m);  // ilqr.py:98 passes u_last = u_t
         total += c;
-        if (a.cost) co[gi<MINOR>(t, T + 1, p, NP)] = c;
-        if (a.action) {
+        if (!FAST && a.cost) co[gi<MINOR>(t, T + 1, p, NP)] = c;
+        if (FAST || a.action) {
 #pragma unroll
             for (int j = 0; j < M; ++j)
                 if (j < m) ac[gi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
             if (i < n) {
                 x[i] = xn[i];
                 fin = fin && (x[i] < 1e8);
-                if (a.state) st[gi<MINOR>((size_t)n * (t + 1) + i, En1, p, NP)] = x[i];
+                if (FAST || a.state) st[gi<MINOR>((size_t)n * (t + 1) + i, En1, p, NP)] = x[i];
             }
     }
     {
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         for (int j = 0; j < M; ++j) zero[j] = 0.0;
         const double c = env_cost<N, M>(e, x, zero, zero, w, n, m);  // ilqr.py:101
         total += c;
-        if (a.cost) co[gi<MINOR>(T, T + 1, p, NP)] = c;
+        if (!FAST && a.cost) co[gi<MINOR>(T, T + 1, p, NP)] = c;
     }
     if (a.ret) a.ret[(size_t)ai * NP + p] = total;
     if (a.finite) a.finite[(size_t)ai * NP + p] = fin ? 1 : 0;
@@ -202,10 +205,13 @@ struct RolloutLaunch {
         const size_t total = a.NP * (size_t)(a.nb_alphas - a.alpha_begin);
         const dim3 grid((unsigned)((total + 63) / 64)), block(64);
         const bool mi = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR, kmi = k_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
-        if (mi && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true>), grid, block, 0, st, a);
-        else if (mi) hipLaunchKernelGGL((rollout_kernel<SYS, true, false>), grid, block, 0, st, a);
-        else if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, false, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((rollout_kernel<SYS, false, false>), grid, block, 0, st, a);
+        const bool fast = a.state && a.action && !a.cost;
+        if (mi && kmi && fast) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true>), grid, block, 0, st, a);
+        else if (mi && fast) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true>), grid, block, 0, st, a);
+        else if (mi && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false>), grid, block, 0, st, a);
+        else if (mi) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, false>), grid, block, 0, st, a);
+        else if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, false, true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((rollout_kernel<SYS, false, false, false>), grid, block, 0, st, a);
     }
 };
 
