@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--instances", type=int, default=4096, help="problems per GPU (C2: 4096)")
     ap.add_argument("--horizon", type=int, default=500)
     ap.add_argument("--env", default="cartpole")
+    ap.add_argument("--staged", type=int, default=-1, help="line search: -1 auto, 0 one launch, 1 staged (same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     a = ap.parse_args()
@@ -126,7 +127,7 @@ def main():
     n, m = env.dm_state, env.dm_act
     x0, kff0 = make_problem_set(env, N, T, 1337 + rank)
     solver = BatchedILQR(env, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False,
-                         tolfun=-float("inf"), tolgrad=0.0, max_lmbda=float("inf"))
+                         tolfun=-float("inf"), tolgrad=0.0, max_lmbda=float("inf"), staged_line_search=a.staged)
     nb_alphas = solver.alphas.size
     solver.init_rollout()
     solver.iterate(W)
@@ -167,11 +168,11 @@ def main():
         achieved = per_launch / (phases[dom] * 1e-3) / 1e9
         bwd_gbs = ab["backward"] * N * T / (phases["backward"] * 1e-3) / 1e9
         # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
-        # separate runs, gfx950 read correction applied; profiles/r01_pmc_traffic_c2.json) - PMC counters cannot
+        # separate runs, gfx950 read correction applied; profiles/r01_c_pmc_traffic_c2.json) - PMC counters cannot
         # be sampled from inside this process, so it is only filled for the workload they were collected on
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_c2.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic_c2.json")))
             if a.env == "cartpole" and N == 4096 and T == 500 and nb_alphas == 11:
                 traffic = pmc["by_phase"].get(dom)
         except (OSError, ValueError, KeyError):

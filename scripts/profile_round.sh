@@ -1,0 +1,21 @@
+#!/bin/bash
+# One GPU call's worth of measurements for profiles/: kernel trace of the bench command, the two PMC passes,
+# the backward pass alone on C1-C5, and the bench at 65 536 instances.  Run from the repo root on the GPU box.
+set -o pipefail
+export TMPDIR=/tmp
+O=gpurun_out/prof
+mkdir -p $O
+timeout -k 10 200 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err || exit 1
+timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o c2 -- python bench.py --no-cpu-baseline > $O/kt.log 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o c2 -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/pmc_fetch.log 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o c2 -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/pmc_write.log 2>&1 || exit 1
+{
+  timeout -k 10 60 python scripts/bench_backward.py --n 2 --m 1 --T 100 --N 1 || exit 1
+  for N in 4096 65536; do timeout -k 10 60 python scripts/bench_backward.py --n 4 --m 1 --T 500 --N $N || exit 1; done
+  for N in 8192 65536; do timeout -k 10 60 python scripts/bench_backward.py --n 6 --m 1 --T 500 --N $N || exit 1; done
+  timeout -k 10 60 python scripts/bench_backward.py --n 12 --m 4 --T 500 --N 4096 --layout 0 || exit 1
+  timeout -k 10 120 python scripts/bench_backward.py --variant riccati --n 64 --m 16 --T 1000 --N 1024 --layout 0 --reps 3 || exit 1
+} > $O/backward_all_configs.log 2>&1
+timeout -k 10 200 python bench.py --no-cpu-baseline --instances 65536 --steps 5 --warmup 2 > $O/bench_65536.json 2> $O/bench_65536.err || exit 1
+timeout -k 10 200 python bench.py --no-cpu-baseline --env double_cartpole --instances 8192 --steps 5 --warmup 2 > $O/bench_c3.json 2> $O/bench_c3.err || exit 1
+echo done

@@ -313,10 +313,12 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         for (int j = 0; j < m; ++j) io.cost_guu[j] = sc * 2.0 * env->uw[j];
     }
     const bool fuse_commit = !opt->keep_value;
-    // staged line search: worth its second 500-step latency chain only once the one-launch form oversubscribes the
-    // chip (1024 SIMDs x 64 lanes); never with argmin (needs every alpha) or a single alpha
+    // staged line search: worth its second 500-step latency chain, and the scattered accesses of its compacted second
+    // stage, only once the one-launch form oversubscribes the chip (1024 SIMDs x 64 lanes) many times over - measured
+    // on 65 536 cartpoles x 11 alphas early in an optimisation (most problems reject alphas[0]): one launch 8.6 ms,
+    // staged 12.6 ms; never with argmin (needs every alpha) or a single alpha
     bool staged = opt->staged_line_search == 1 ||
-                  (opt->staged_line_search < 0 && (int64_t)NP * opt->nb_alphas >= 4 * 65536);
+                  (opt->staged_line_search < 0 && (int64_t)NP * opt->nb_alphas >= 16 * 65536);
     if (opt->argmin_alpha || opt->nb_alphas < 2 || !ws->pending_list || !ws->pending_count) staged = false;
     const QuadCommit cm{ws->sel, ws->cand_state, ws->cand_action, ws->cand_K, ws->cand_kff,
                         ws->xref, ws->uref, ws->K, ws->kff};
