@@ -105,10 +105,14 @@ __device__ __forceinline__ void sincos_g(double x, double& s, double& c) {
     pc = fma(z, pc, 4.16666666666666019037e-02);
     const double sr = fma(r * z, ps, r);
     const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    // quadrant: swap for odd q, then flip the sign bits - integer ops on the high words, no fp64 selects of negations
     const int q = (int)fk;
-    const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
-    s = (q & 2) ? -s0 : s0;
-    c = ((q + 1) & 2) ? -c0 : c0;
+    const bool odd = (q & 1) != 0;
+    const double s0 = odd ? cr : sr, c0 = odd ? sr : cr;
+    const unsigned sflip = ((unsigned)q << 30) & 0x80000000u;          // q & 2
+    const unsigned cflip = ((unsigned)(q + 1) << 30) & 0x80000000u;    // (q + 1) & 2
+    s = __hiloint2double(__double2hiint(s0) ^ (int)sflip, __double2loint(s0));
+    c = __hiloint2double(__double2hiint(c0) ^ (int)cflip, __double2loint(c0));
 }
 template <int K> __device__ __forceinline__ void sincos_g(const Dual<K>& x, Dual<K>& s, Dual<K>& c) {
     double sv, cv;
@@ -237,13 +241,15 @@ template <> struct Model<TRAJOPT_ENV_QUADROTOR> {
 };
 
 // env.dynamics(x, u): clip(u) -> RK4(dt) -> clip(xn)       (cartpole.py:62-97)
-template <int MODEL, class X>
+// UCLIP = false: the caller has already clipped u to +-umax (the rollout's control law does, ilqr.py:97; clipping
+// twice is the identity) - three instructions less in a chain of dependent ones.
+template <int MODEL, class X, bool UCLIP = true>
 __device__ __forceinline__ void env_dynamics(const trajopt_env_t& e, const X (&x)[Model<MODEL>::N],
                                              const X (&u)[Model<MODEL>::M], X (&xn)[Model<MODEL>::N]) {
     constexpr int N = Model<MODEL>::N, M = Model<MODEL>::M;
     X uc[M];
 #pragma unroll
-    for (int j = 0; j < M; ++j) uc[j] = clip_g(u[j], e.umax[j]);
+    for (int j = 0; j < M; ++j) uc[j] = UCLIP ? clip_g(u[j], e.umax[j]) : u[j];
     const double dt = e.dt;
     X k1[N], k2[N], k3[N], k4[N], y[N];
     Model<MODEL>::f(e, x, uc, k1);
@@ -297,6 +303,25 @@ __device__ __forceinline__ double wrap_angle(double x) {
     r = (r < 0.0) ? r + two_pi : r;
     r = (r >= two_pi) ? r - two_pi : r;
     return r - M_PI;
+}
+
+// env.cost(x, u, u, a) for the plain case - no slew-rate cost, no angle wrapping, no dt scaling (the three flags are
+// wave-uniform, but testing them every step costs a lone wave ~20 instructions of a 470-instruction step).
+template <int N, int M>
+__device__ __forceinline__ double env_cost_plain(const trajopt_env_t& e, const double (&x)[N], const double (&u)[M], double a) {
+    double c = 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) c = fma(u[j] * e.uw[j], u[j], c);
+    if (a != 0.0) {  // Python `if a:` drops the state cost for an exactly-zero weight
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double r = x[i] - e.goal[i];
+            s = fma(r * e.gw[i], r, s);
+        }
+        c = fma(a, s, c);
+    }
+    return c;
 }
 
 // env.cost(x, u, u_last, a) with identity features (cartpole.py:112-127; LQR: lqr_v0.py:89-94).

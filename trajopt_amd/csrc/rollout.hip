@@ -36,8 +36,8 @@ __device__ __forceinline__ size_t gi(size_t e_total, size_t E_total, size_t p, s
 
 // MINOR: layout of x0 / xref / uref / candidates;  KMINOR: layout of the gains K, kff (the batched driver keeps
 // them PROBLEM_MAJOR for the matrix-core backward kernel when dx > 6).
-// FAST: the batched driver's call - state and action planes given, no per-step cost plane - with the stores
-// unconditional: a store under a (wave-uniform) `if (pointer)` makes the waitcnt pass wait for EVERY outstanding
+// FAST: the batched driver's call - state and action planes given, no per-step cost plane, plain cost (no slew rate,
+// no angle wrapping, no dt scaling) - with the stores unconditional: a store under a (wave-uniform) `if (pointer)` makes the waitcnt pass wait for EVERY outstanding
 // memory operation (vmcnt(0)) before the prefetched gains are used, i.e. for this step's stores to be acknowledged.
 template <class SYS, bool MINOR, bool KMINOR, bool FAST>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
@@ -83,6 +83,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         ev.slew_rate = a.env.slew_rate;  // flags stay wave-uniform so that their branches stay scalar
         ev.periodic = a.env.periodic;
         ev.cost_times_dt = a.env.cost_times_dt;
+        // x + 0.0 is an arithmetic result, i.e. canonical: fmin / fmax against it need no v_max(x, x) quieting per use
+#pragma unroll
+        for (int j = 0; j < M; ++j) ev.umax[j] += 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) ev.xmax[i] += 0.0;
     }
     const trajopt_env_t& e = SYS::kStatic ? ev : a.env;
     const int n = SYS::n(e), m = SYS::m(e), T = a.T;
@@ -135,7 +140,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         const double wt = w;
         if (t + 1 < T) load(t + 1);  // prefetch the next step's gains while this one integrates
         w = a.weighting[t + 1];
-        const double c = env_cost<N, M>(e, x, u, u, wt, n, m);  // ilqr.py:98 passes u_last = u_t
+        double c;
+        if constexpr (FAST) c = env_cost_plain<N, M>(e, x, u, wt);
+        else c = env_cost<N, M>(e, x, u, u, wt, n, m);  // ilqr.py:98 passes u_last = u_t
         total += c;
         if (!FAST && a.cost) co[gi<MINOR>(t, T + 1, p, NP)] = c;
         if (FAST || a.action) {
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 if (j < m) ac[gi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
         }
         double xn[N];
-        SYS::dynamics(e, x, u, xn);
+        SYS::dynamics_clipped(e, x, u, xn);  // u is clipped above
 #pragma unroll
         for (int i = 0; i < N; ++i)
             if (i < n) {
@@ -157,7 +164,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         double zero[M];
 #pragma unroll
         for (int j = 0; j < M; ++j) zero[j] = 0.0;
-        const double c = env_cost<N, M>(e, x, zero, zero, w, n, m);  // ilqr.py:101
+        double c;
+        if constexpr (FAST) c = env_cost_plain<N, M>(e, x, zero, w);
+        else c = env_cost<N, M>(e, x, zero, zero, w, n, m);  // ilqr.py:101
         total += c;
         if (!FAST && a.cost) co[gi<MINOR>(T, T + 1, p, NP)] = c;
     }
@@ -205,7 +214,8 @@ struct RolloutLaunch {
         const size_t total = a.NP * (size_t)(a.nb_alphas - a.alpha_begin);
         const dim3 grid((unsigned)((total + 63) / 64)), block(64);
         const bool mi = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR, kmi = k_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
-        const bool fast = a.state && a.action && !a.cost;
+        const bool fast = SYS::kStatic && a.state && a.action && !a.cost && !a.env.slew_rate && a.env.periodic == 0 &&
+                          !a.env.cost_times_dt;
         if (mi && kmi && fast) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true>), grid, block, 0, st, a);
         else if (mi && fast) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true>), grid, block, 0, st, a);
         else if (mi && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false>), grid, block, 0, st, a);

@@ -15,6 +15,11 @@ struct SysPhys {
                                                     double (&xn)[N]) {
         env_dynamics<MODEL, double>(e, x, u, xn);
     }
+    // same for an action already clipped to +-umax
+    static __device__ __forceinline__ void dynamics_clipped(const trajopt_env_t& e, const double (&x)[N],
+                                                            const double (&u)[M], double (&xn)[N]) {
+        env_dynamics<MODEL, double, false>(e, x, u, xn);
+    }
     // Columns [k0, k0+KC) of the Jacobian [A | B] of env.dynamics at (x, u): J[i][k - k0].
     template <int KC>
     static __device__ __forceinline__ void jacobian_cols(const trajopt_env_t& e, const double (&x)[N],
@@ -47,6 +52,10 @@ struct SysLqr {
     static __device__ __forceinline__ int m(const trajopt_env_t& e) { return e.dm_act; }
     static __device__ __forceinline__ void dynamics(const trajopt_env_t& e, const double (&x)[N], const double (&u)[M],
                                                     double (&xn)[N]) {
+        lqr_dynamics<double>(e, x, u, xn);
+    }
+    static __device__ __forceinline__ void dynamics_clipped(const trajopt_env_t& e, const double (&x)[N],
+                                                            const double (&u)[M], double (&xn)[N]) {
         lqr_dynamics<double>(e, x, u, xn);
     }
     template <int KC>
