@@ -108,6 +108,89 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
             fin = fin && (x[i] < 1e8);
             if (FAST || a.state) st[gi<MINOR>(i, En1, p, NP)] = x[i];
         }
+    if constexpr (FAST) {
+        // The driver's variant.  Addresses are a wave-uniform slice pointer per array (advanced with scalar adds) plus
+        // a constant 32-bit per-lane offset per element, and the gains of step t+1 are loaded into the OTHER of two
+        // named register sets while step t integrates (unconditionally: the last slice is simply loaded twice) - the
+        // generic loop below costs ~65 address / copy instructions per step, a sixth of the step.
+        static_assert(MINOR && SYS::kStatic, "FAST is instantiated for the struct-of-arrays layout and static dimensions only");
+        struct In { double xr[N], ur[M], kf[M], K[M * N], w; };
+        const unsigned np8 = (unsigned)(NP * 8), p8 = (unsigned)(p * 8);
+        unsigned ox[N], ou[M], okf[M], oK[M * N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) ox[i] = (unsigned)i * np8 + p8;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            ou[j] = (unsigned)j * np8 + p8;
+            okf[j] = KMINOR ? ou[j] : (unsigned)((p * Em + j) * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < M * N; ++k) oK[k] = KMINOR ? (unsigned)k * np8 + p8 : (unsigned)((p * Enm + k) * 8);
+        const size_t sx = (size_t)N * np8, su = (size_t)M * np8, skf = KMINOR ? su : (size_t)M * 8,
+                     sK = KMINOR ? (size_t)N * M * np8 : (size_t)N * M * 8;
+        const char *pxr = reinterpret_cast<const char*>(a.xref), *pur = reinterpret_cast<const char*>(a.uref),
+                   *pK = reinterpret_cast<const char*>(a.K), *pkf = reinterpret_cast<const char*>(a.kff),
+                   *pw = reinterpret_cast<const char*>(a.weighting);
+        auto ld = [](const char* b, unsigned o) { return *reinterpret_cast<const double*>(b + o); };
+        int tl = 0;  // the slice the pointers address
+        auto load = [&](In& s) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) s.xr[i] = ld(pxr, ox[i]);
+#pragma unroll
+            for (int j = 0; j < M; ++j) { s.ur[j] = ld(pur, ou[j]); s.kf[j] = ld(pkf, okf[j]); }
+#pragma unroll
+            for (int k = 0; k < M * N; ++k) s.K[k] = ld(pK, oK[k]);
+            s.w = ld(pw, 0u);
+            if (tl + 1 < T) { pxr += sx; pur += su; pK += sK; pkf += skf; pw += 8; ++tl; }
+        };
+        double* sp[N];
+        double* ap[M];
+#pragma unroll
+        for (int i = 0; i < N; ++i) sp[i] = st + ((size_t)i * NP + p);
+#pragma unroll
+        for (int j = 0; j < M; ++j) ap[j] = ac + ((size_t)j * NP + p);
+        const size_t dsx = (size_t)N * NP, dsu = (size_t)M * NP;
+        auto step = [&](const In& s) {
+            double u[M];  // u = clip(uref + alpha kff + K (x - xref))    objects.py:137-139, ilqr.py:97
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                double kx = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) kx = fma(s.K[j + M * i], x[i] - s.xr[i], kx);
+                u[j] = clip_g(fma(alpha, s.kf[j], s.ur[j]) + kx, e.umax[j]);
+            }
+            total += env_cost_plain<N, M>(e, x, u, s.w);  // ilqr.py:98 passes u_last = u_t
+#pragma unroll
+            for (int j = 0; j < M; ++j) { *ap[j] = u[j]; ap[j] += dsu; }
+            double xn[N];
+            SYS::dynamics_clipped(e, x, u, xn);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                x[i] = xn[i];
+                fin = fin && (x[i] < 1e8);
+                sp[i] += dsx;
+                *sp[i] = x[i];
+            }
+        };
+        In sa, sb;
+        load(sa);
+        int t = 0;
+        while (t < T) {
+            load(sb);
+            step(sa);
+            if (++t >= T) break;
+            load(sa);
+            step(sb);
+            ++t;
+        }
+        double zero[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) zero[j] = 0.0;
+        total += env_cost_plain<N, M>(e, x, zero, a.weighting[T]);  // ilqr.py:101
+        if (a.ret) a.ret[(size_t)ai * NP + p] = total;
+        if (a.finite) a.finite[(size_t)ai * NP + p] = fin ? 1 : 0;
+        return;
+    }
     auto load = [&](int t) {
 #pragma unroll
         for (int i = 0; i < N; ++i)
@@ -140,12 +223,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         const double wt = w;
         if (t + 1 < T) load(t + 1);  // prefetch the next step's gains while this one integrates
         w = a.weighting[t + 1];
-        double c;
-        if constexpr (FAST) c = env_cost_plain<N, M>(e, x, u, wt);
-        else c = env_cost<N, M>(e, x, u, u, wt, n, m);  // ilqr.py:98 passes u_last = u_t
+        const double c = env_cost<N, M>(e, x, u, u, wt, n, m);  // ilqr.py:98 passes u_last = u_t
         total += c;
-        if (!FAST && a.cost) co[gi<MINOR>(t, T + 1, p, NP)] = c;
-        if (FAST || a.action) {
+        if (a.cost) co[gi<MINOR>(t, T + 1, p, NP)] = c;
+        if (a.action) {
 #pragma unroll
             for (int j = 0; j < M; ++j)
                 if (j < m) ac[gi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
@@ -157,18 +238,16 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
             if (i < n) {
                 x[i] = xn[i];
                 fin = fin && (x[i] < 1e8);
-                if (FAST || a.state) st[gi<MINOR>((size_t)n * (t + 1) + i, En1, p, NP)] = x[i];
+                if (a.state) st[gi<MINOR>((size_t)n * (t + 1) + i, En1, p, NP)] = x[i];
             }
     }
     {
         double zero[M];
 #pragma unroll
         for (int j = 0; j < M; ++j) zero[j] = 0.0;
-        double c;
-        if constexpr (FAST) c = env_cost_plain<N, M>(e, x, zero, w);
-        else c = env_cost<N, M>(e, x, zero, zero, w, n, m);  // ilqr.py:101
+        const double c = env_cost<N, M>(e, x, zero, zero, w, n, m);  // ilqr.py:101
         total += c;
-        if (!FAST && a.cost) co[gi<MINOR>(T, T + 1, p, NP)] = c;
+        if (a.cost) co[gi<MINOR>(T, T + 1, p, NP)] = c;
     }
     if (a.ret) a.ret[(size_t)ai * NP + p] = total;
     if (a.finite) a.finite[(size_t)ai * NP + p] = fin ? 1 : 0;
@@ -214,11 +293,19 @@ struct RolloutLaunch {
         const size_t total = a.NP * (size_t)(a.nb_alphas - a.alpha_begin);
         const dim3 grid((unsigned)((total + 63) / 64)), block(64);
         const bool mi = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR, kmi = k_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
+        // (FAST addresses the gains with 32-bit per-lane byte offsets)
+        const double kbytes = kmi ? (double)SYS::N * SYS::M * (double)a.NP * 8.0
+                                  : (double)a.NP * SYS::N * SYS::M * (double)a.T * 8.0;
         const bool fast = SYS::kStatic && a.state && a.action && !a.cost && !a.env.slew_rate && a.env.periodic == 0 &&
-                          !a.env.cost_times_dt;
-        if (mi && kmi && fast) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true>), grid, block, 0, st, a);
-        else if (mi && fast) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true>), grid, block, 0, st, a);
-        else if (mi && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false>), grid, block, 0, st, a);
+                          !a.env.cost_times_dt && a.T > 0 && kbytes + (double)a.NP * 8.0 < 4294967296.0;
+        if constexpr (SYS::kStatic) {
+            if (mi && fast) {
+                if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true>), grid, block, 0, st, a);
+                return;
+            }
+        }
+        if (mi && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false>), grid, block, 0, st, a);
         else if (mi) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, false>), grid, block, 0, st, a);
         else if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, false, true, false>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((rollout_kernel<SYS, false, false, false>), grid, block, 0, st, a);
