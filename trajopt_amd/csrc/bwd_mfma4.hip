@@ -58,9 +58,16 @@ __device__ __forceinline__ void m4_st(double x, double* base, unsigned off) {
     *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off) = x;
 }
 
-struct M4In {  // one step's inputs, each already in the lane layout of the operand it feeds
-    double A, BR, Cxx, CxuR, cxR, CuuF, cuF, urF;
-    double wF;      // structured cost only: the weighting w[t], in place of Cxx, CxuR, CuuF
+// One step's inputs.  A (and, for a dense cost, Cxx) are loaded in the lane layout of the operand they feed.  All the
+// vectors and scalars of the step travel in ONE packed register P, a 4 x 4 tile per problem,
+//     row 0: B[0..3]    row 1: cx[0..3]    row 2: cu, uref, (w[t] | Cuu), -    row 3: Cxu[0..3] (dense cost only)
+// and the matrix cores replicate them into the layouts the step needs (with e_k the register "1 where r == k"):
+//     mfma(P, e_k, 0)[i][j] = P[k][i]   (row k as an "R" vector)      mfma(e_k, X, 0)[i][j] = X[k][j]
+// because the texture addressers take a quarter-wave per cycle whatever the addresses: seven loads per step cost every
+// wave 112 cycles of the CU's one address pipeline, two cost 32, and the six extra matrix instructions are off the
+// critical path.
+struct M4In {
+    double A, P, Cxx;
 };
 constexpr int kRing = 7;  // prefetch distance in steps
 
@@ -69,27 +76,16 @@ struct M4Off {
     unsigned rc, r, c, z;
 };
 
-// SC: structured cost (trajopt_backward_io_t::cost_w) - Cxx = w[t] diag(gxx), Cuu = guu, Cxu = 0 are not loaded;
-// `wofs` is the byte offset of w[t] (the same for every lane: one line).
-template <int N, bool GN, bool SC>
-__device__ __forceinline__ void m4_load(M4In& s, const trajopt_backward_io_t& io, const M4Off& o, unsigned wofs,
-                                        bool in_rc, bool in_r) {
+// SC: structured cost (trajopt_backward_io_t::cost_w) - Cxx = w[t] diag(gxx), Cuu = guu, Cxu = 0 are not loaded.
+// `pp` is the lane's own address inside P's source array for the slice being loaded.
+template <int N, bool SC>
+__device__ __forceinline__ void m4_load(M4In& s, const trajopt_backward_io_t& io, const M4Off& o, const char* pp,
+                                        bool in_rc, bool p_live) {
+    // loads only: the padding lanes (which read a valid address) are zeroed where the values are used - a select
+    // here would make the wave wait for the load it has just issued
     s.A = m4_ld(io.A, o.rc);
-    s.BR = m4_ld(io.B, o.r);
-    if constexpr (SC) {
-        s.wF = m4_ld(io.cost_w, wofs);
-    } else {
-        s.Cxx = m4_ld(io.Cxx, o.rc);
-        s.CxuR = m4_ld(io.Cxu, o.r);
-        s.CuuF = m4_ld(io.Cuu, o.z);
-    }
-    s.cxR = m4_ld(io.cx, o.r);
-    s.cuF = m4_ld(io.cu, o.z);
-    if constexpr (GN) s.urF = m4_ld(io.uref, o.z);
-    if constexpr (N < 4) {  // padding lanes of a smaller state: zero rows / columns
-        if (!in_rc) { s.A = 0.0; if constexpr (!SC) s.Cxx = 0.0; }
-        if (!in_r) { s.BR = 0.0; s.cxR = 0.0; if constexpr (!SC) s.CxuR = 0.0; }
-    }
+    s.P = *reinterpret_cast<const double*>(pp);
+    if constexpr (!SC) s.Cxx = m4_ld(io.Cxx, o.rc);
 }
 
 // REG: 1 / 2 = the reference's regularisation modes (util.cpp:135-143), 0 = none (any other value of `reg`).
@@ -130,6 +126,35 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
     // structured cost: Cxx[t] = w[t] dg with dg = diag(gxx) in the C-operand layout, Cuu = guu
     const double dg = (SC && r == c && in_r) ? io.cost_gxx[r] : 0.0;
     const double guu = SC ? io.cost_guu[0] : 0.0;
+    const double e0 = r == 0 ? 1.0 : 0.0, e1 = r == 1 ? 1.0 : 0.0, e2 = r == 2 ? 1.0 : 0.0, e3 = r == 3 ? 1.0 : 0.0;
+    // the lane's slot of the packed tile P: source array, byte offset inside slice 0, bytes per slice
+    const char* p_base;
+    size_t p_off, p_stride;
+    bool p_live = true;
+    {
+        const size_t vec_off = ((size_t)cc * NP + p) * 8, vec_stride = (size_t)N * NP * 8;  // element c of an n-vector
+        const size_t sc_off = p * 8, sc_stride = NP * 8;                                    // a per-problem scalar
+        p_base = reinterpret_cast<const char*>(io.B); p_off = vec_off; p_stride = vec_stride;
+        if (r == 0) {
+            p_live = in_c;
+        } else if (r == 1) {
+            p_base = reinterpret_cast<const char*>(io.cx); p_live = in_c;
+        } else if (r == 2) {
+            p_base = reinterpret_cast<const char*>(io.cu); p_off = sc_off; p_stride = sc_stride;
+            if (c == 1) {
+                if (GN) p_base = reinterpret_cast<const char*>(io.uref);
+                p_live = GN;
+            } else if (c == 2) {
+                if (SC) { p_base = reinterpret_cast<const char*>(io.cost_w); p_off = 0; p_stride = 8; }
+                else p_base = reinterpret_cast<const char*>(io.Cuu);
+            } else if (c == 3) {
+                p_live = false;
+            }
+        } else {
+            if (!SC) p_base = reinterpret_cast<const char*>(io.Cxu);
+            p_live = !SC && in_c;
+        }
+    }
 
     for (;;) {
         bool alive = !frozen;
@@ -155,36 +180,46 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
             VT = m4_mm(VTerm, eye, 0.0);
         }
         M4Off ol = slice(T - 1), os = ol;  // slice being loaded / slice being computed and stored
-        unsigned wl = (unsigned)(T - 1) * 8u;  // byte offset of w[slice being loaded]
+        const char* pl = p_base + p_off + (size_t)(T - 1) * p_stride;  // the lane's slot of P in the slice being loaded
         M4In ring[kRing];
 #pragma unroll
         for (int k = 0; k < kRing; ++k) {
             // unconditional (a load under a branch makes the waitcnt pass drain the queue at the loop header): a
             // horizon shorter than the ring re-loads slice 0 into the slots it never uses
-            m4_load<N, GN, SC>(ring[k], io, ol, wl, in_rc, in_r);
-            if (T - 2 - k >= 0) { back(ol); wl -= 8u; }
+            m4_load<N, SC>(ring[k], io, ol, pl, in_rc, p_live);
+            if (T - 2 - k >= 0) { back(ol); pl -= p_stride; }
             // keep the prologue's loads in slot order, the order the loop refills them in: the waitcnt pass merges
             // both at the loop header and otherwise drains every load (vmcnt(0)) once per trip round the ring
             __builtin_amdgcn_sched_barrier(0);
         }
 
-        auto step = [&](const M4In& in, int t) {
-            const double ZR = m4_mm(VT, in.BR, 0.0);
+        auto step = [&](const M4In& raw, int t) {
+            // unpack P (independent of V: the scheduler is free to run these ahead of the chain)
+            M4In in = raw;
+            if (!p_live) in.P = 0.0;  // unused slots of the packed tile
+            if constexpr (N < 4) {    // padding lanes of a smaller state: zero rows / columns
+                if (!in_rc) { in.A = 0.0; if constexpr (!SC) in.Cxx = 0.0; }
+            }
+            const double BR = m4_mm(in.P, e0, 0.0), cxR = m4_mm(in.P, e1, 0.0), row2 = m4_mm(in.P, e2, 0.0);
+            const double cuF = m4_mm(e0, row2, 0.0), x22F = m4_mm(e2, row2, 0.0);  // x22 = w[t] (SC) or Cuu
+            const double urF = GN ? m4_mm(e1, row2, 0.0) : 0.0;
+            const double CxuR = SC ? 0.0 : m4_mm(in.P, e3, 0.0);
+            const double ZR = m4_mm(VT, BR, 0.0);
             const double P0 = m4_mm(VT, in.A, 0.0);
-            const double quF = m4_mm(in.BR, vR, in.cuF);
-            const double qxR = m4_mm(in.A, vR, in.cxR);
-            const double QuuF = m4_mm(in.BR, ZR, SC ? guu : in.CuuF);
-            const double QxuR = m4_mm(in.A, ZR, SC ? 0.0 : in.CxuR);
-            const double Qxx = m4_mm(in.A, P0, SC ? in.wF * dg : in.Cxx);
+            const double quF = m4_mm(BR, vR, cuF);
+            const double qxR = m4_mm(in.A, vR, cxR);
+            const double QuuF = m4_mm(BR, ZR, SC ? guu : x22F);
+            const double QxuR = m4_mm(in.A, ZR, CxuR);
+            const double Qxx = m4_mm(in.A, P0, SC ? x22F * dg : in.Cxx);
             const double QxuC = m4_mm(QxuR, eye, 0.0);  // D[i][j] = Qxu[j]
             const double Qs = m4_mm(Qxx, eye, Qxx);     // Qxx + Qxx' (one rounding per entry: bitwise symmetric)
             // regularisation (util.cpp:135-143)
             double q_reg = QuuF, QxuR_r = QxuR, QxuC_r = QxuC;
             if constexpr (REG == 2) {  // (V + lam I): Qux_reg = Qux + lam B'A, Quu_reg = Quu + lam B'B
-                const double BAr = m4_mm(in.A, in.BR, 0.0);
+                const double BAr = m4_mm(in.A, BR, 0.0);
                 QxuR_r = fma(lam, BAr, QxuR);
                 QxuC_r = fma(lam, m4_mm(BAr, eye, 0.0), QxuC);
-                q_reg = fma(lam, m4_mm(in.BR, in.BR, 0.0), QuuF);
+                q_reg = fma(lam, m4_mm(BR, BR, 0.0), QuuF);
             } else if constexpr (REG == 1) {
                 q_reg = QuuF + lam;
             }
@@ -231,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
                     if (st_r && io.v) m4_st(vR, io.v, os.r);
                 }
                 if constexpr (GN) {  // ilqr.py:176; NaN-propagating max: gnan turns NaN once any ratio is NaN
-                    const double d = fabs(in.urF) + 1.0;
+                    const double d = fabs(urF) + 1.0;
                     double ri = __builtin_amdgcn_rcp(d);
                     ri = fma(ri, fma(-d, ri, 1.0), ri);
                     const double g = fabs(kff) * ri;
@@ -252,8 +287,8 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
 #pragma unroll
             for (int k = 0; k < kRing; ++k) {
                 step(ring[k], t);
-                m4_load<N, GN, SC>(ring[k], io, ol, wl, in_rc, in_r);
-                if (!a.dbg_same_step) { back(ol); wl -= 8u; }
+                m4_load<N, SC>(ring[k], io, ol, pl, in_rc, p_live);
+                if (!a.dbg_same_step) { back(ol); pl -= p_stride; }
                 --t;
             }
         }
@@ -262,9 +297,9 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
             if (t >= 0) {
                 step(ring[k % kRing], t);
                 if (k < kRing - 1 && t - kRing >= 0) {
-                    m4_load<N, GN, SC>(ring[k % kRing], io, ol, wl, in_rc, in_r);
+                    m4_load<N, SC>(ring[k % kRing], io, ol, pl, in_rc, p_live);
                     back(ol);
-                    wl -= 8u;
+                    pl -= p_stride;
                 }
                 --t;
             }
