@@ -4,6 +4,7 @@
 //   pendulum         /root/reference/trajopt/envs/pendulum/pendulum.py:58-76 (dynamics), :111-125 (cost)
 //   cartpole         /root/reference/trajopt/envs/cartpole/cartpole.py:62-97, :112-127
 //   double cartpole  /root/reference/trajopt/envs/double_cartpole/double_cartpole.py:61-155, :170-187
+//   double pendulum  /root/reference/trajopt/envs/double_pendulum/double_pendulum.py:61-125, :140-154
 //   LQR (affine LTI) /root/reference/trajopt/envs/lqr/lqr_v0.py:50-66, :89-94
 //   quadrotor        build-defined 12-state rigid body (NOT in the reference; SURVEY "Facts", C4)
 // and of the autograd derivatives the reference takes of them (objects.py:58-63,108-109): forward-mode
@@ -117,6 +118,27 @@ template <class X> void f_double_cartpole(const trajopt_env_t& e, const X* x, co
     }
     dx[0] = dq; dx[1] = dth1; dx[2] = dth2; dx[3] = dd[0]; dx[4] = dd[1]; dx[5] = dd[2];
 }
+template <class X> void f_double_pendulum(const trajopt_env_t& e, const X* x, const X* u, X* dx) {
+    // double_pendulum.py:66-113, term by term
+    const double g = e.phys[0], m1 = e.phys[1], m2 = e.phys[2], l1 = e.phys[3], l2 = e.phys[4], k1 = e.phys[5],
+                 k2 = e.phys[6];
+    const double I1 = m1 * (l1 * l1 + 1e-4) / 3.0, I2 = m2 * (l2 * l2 + 1e-4) / 3.0;
+    const double l1CM = l1 / 2., l2CM = l2 / 2.;
+    X th1 = x[0] + M_PI, th2 = x[1], dth1 = x[2], dth2 = x[3];
+    X s1 = sin(th1), c1 = cos(th1), s2 = sin(th2), c2 = cos(th2);
+    X h11 = I1 + I2 + l1CM * l1CM * m1 + l1 * l1 * m2 + l2CM * l2CM * m2 + 2. * l1 * l2CM * m2 * c2;
+    X h12 = I2 + l2CM * l2CM * m2 + l1 * l2CM * m2 * c2;
+    X b1 = g * l1CM * m1 * s1 + g * l1 * m2 * s1 + g * l2CM * m2 * c2 * s1 - 2. * dth1 * dth2 * l1 * l2CM * m2 * s2 -
+           dth2 * dth2 * l1 * l2CM * m2 * s2 + g * l2CM * m2 * c1 * s2;
+    X h21 = I2 + l2CM * l2CM * m2 + l1 * l2CM * m2 * c2;
+    X h22 = X(I2 + l2CM * l2CM * m2);
+    X b2 = g * l2CM * m2 * c2 * s1 + dth1 * dth1 * l1 * l2CM * m2 * s2 + g * l2CM * m2 * c1 * s2;
+    X u1 = u[0] - k1 * dth1, u2 = u[1] - k2 * dth2;
+    X det = h11 * h22 - h12 * h21;
+    dx[0] = dth1; dx[1] = dth2;
+    dx[2] = (h22 * (u1 - b1) - h12 * (u2 - b2)) / det;
+    dx[3] = (h11 * (u2 - b2) - h21 * (u1 - b1)) / det;
+}
 template <class X> void f_quadrotor(const trajopt_env_t& e, const X* x, const X* u, X* dx) {
     // build-defined: x = [p(3), euler phi/theta/psi, v(3) world, body rates p q r], u = 4 rotor thrusts
     const double g = e.phys[0], mass = e.phys[1], L = e.phys[2], Ixx = e.phys[3], Iyy = e.phys[4],
@@ -144,6 +166,7 @@ template <class X> void vector_field(const trajopt_env_t& e, const X* x, const X
         case TRAJOPT_ENV_CARTPOLE: f_cartpole(e, x, u, dx); break;
         case TRAJOPT_ENV_DOUBLE_CARTPOLE: f_double_cartpole(e, x, u, dx); break;
         case TRAJOPT_ENV_QUADROTOR: f_quadrotor(e, x, u, dx); break;
+        case TRAJOPT_ENV_DOUBLE_PENDULUM: f_double_pendulum(e, x, u, dx); break;
         default: break;
     }
 }

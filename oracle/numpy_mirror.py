@@ -126,6 +126,11 @@ class Env:
             self.umax, self.xmax = np.array([5.]), np.array([10.] + [inf] * 5)
             self.g, self.gw, self.uw = np.zeros(6), np.array([1e1, 1e4, 1e4, 1e0, 1e0, 1e0]), np.array([1e-5])
             self.angles = [1, 2]
+        elif name == "double_pendulum":
+            self.n, self.m, self.dt = 4, 2, 0.01
+            self.umax, self.xmax = np.array([10., 10.]), np.full(4, inf)
+            self.g, self.gw, self.uw = np.zeros(4), np.array([1e4, 1e4, 1e0, 1e0]), np.full(2, 1e-5)
+            self.angles = [0]
         elif name == "lqr":
             self.A = np.asarray(kw.get("A", [[1.1, 0.], [1.0, 1.0]]), dtype=float)
             self.B = np.asarray(kw.get("B", [[1.], [0.]]), dtype=float)
@@ -188,6 +193,21 @@ class Env:
             act = np.array([u[0], 0., 0.])
             dd = np.linalg.solve(M, act - Cm @ np.array([dq, dth1, dth2]) - G)
             return np.concatenate([np.array([dq, dth1, dth2]), dd])
+        if nm == "double_pendulum":
+            g, m1, m2, l1, l2, k1, k2 = 9.81, 1., 1., 1., 1., 0.025, 0.025
+            I1, I2 = m1 * (l1 ** 2 + 1e-4) / 3., m2 * (l2 ** 2 + 1e-4) / 3.
+            a1, a2 = l1 / 2., l2 / 2.
+            th1, th2, dth1, dth2 = x[0] + np.pi, x[1], x[2], x[3]
+            s1, c1, s2, c2 = np.sin(th1), np.cos(th1), np.sin(th2), np.cos(th2)
+            H = np.array([[I1 + I2 + a1 ** 2 * m1 + l1 ** 2 * m2 + a2 ** 2 * m2 + 2. * l1 * a2 * m2 * c2,
+                           I2 + a2 ** 2 * m2 + l1 * a2 * m2 * c2],
+                          [I2 + a2 ** 2 * m2 + l1 * a2 * m2 * c2, I2 + a2 ** 2 * m2]])
+            b = np.array([g * a1 * m1 * s1 + g * l1 * m2 * s1 + g * a2 * m2 * c2 * s1
+                          - 2. * dth1 * dth2 * l1 * a2 * m2 * s2 - dth2 ** 2 * l1 * a2 * m2 * s2 + g * a2 * m2 * c1 * s2,
+                          g * a2 * m2 * c2 * s1 + dth1 ** 2 * l1 * a2 * m2 * s2 + g * a2 * m2 * c1 * s2])
+            tau = np.array([u[0] - k1 * dth1, u[1] - k2 * dth2])
+            dd = np.linalg.solve(H, tau - b)    # (h22 r1 - h12 r2) / det etc. is Cramer's rule for this system
+            return np.array([dth1, dth2, dd[0], dd[1]])
         if nm == "quadrotor":
             g, mass, L, Ixx, Iyy, Izz, kM = 9.81, 0.5, 0.25, 3.9e-3, 3.9e-3, 7.5e-3, 1.6e-2
             ph, th, ps = x[3], x[4], x[5]

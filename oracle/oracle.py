@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 MAX_STATE, MAX_ACT = 12, 4
-ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR = 1, 2, 3, 4, 5
+ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR, ENV_DOUBLE_PENDULUM = 1, 2, 3, 4, 5, 6
 
 
 class EnvStruct(C.Structure):
@@ -107,6 +107,13 @@ def make_env(name, dt=None, uw=None, slew_rate=False, periodic=False, **kw):
         fill(e.gw, kw.get("gw", [1e1] * n)); fill(e.uw, [1e0] * m if uw is None else uw)
         fill(e.lin_A, A.flatten(order="F")); fill(e.lin_B, B.flatten(order="F"))
         fill(e.lin_c, kw.get("c", -A @ g))
+    elif name == "double_pendulum":  # envs/double_pendulum/double_pendulum.py:17-46,66-70
+        e.model, e.dm_state, e.dm_act = ENV_DOUBLE_PENDULUM, 4, 2
+        e.dt = 0.01 if dt is None else dt
+        fill(e.umax, [10., 10.]); fill(e.xmax, [inf] * 4); fill(e.goal, [0.] * 4)
+        fill(e.gw, [1e4, 1e4, 1e0, 1e0]); fill(e.uw, [1e-5] * 2 if uw is None else uw)
+        fill(e.phys, [9.81, 1., 1., 1., 1., 0.025, 0.025])
+        e.periodic = 0b0001 if periodic else 0
     elif name == "quadrotor":  # build-defined, not in the reference
         e.model, e.dm_state, e.dm_act = ENV_QUADROTOR, 12, 4
         e.dt = 0.01 if dt is None else dt

@@ -49,7 +49,8 @@ def test_env_registry_and_struct():
     from oracle import oracle as O
     from trajopt_amd import envs
     for name, ref_id in (("pendulum", "Pendulum-TO-v0"), ("cartpole", "Cartpole-TO-v0"),
-                         ("double_cartpole", "DoubleCartpole-TO-v0"), ("lqr", "LQR-TO-v0")):
+                         ("double_cartpole", "DoubleCartpole-TO-v0"), ("lqr", "LQR-TO-v0"),
+                         ("double_pendulum", "DoublePendulum-TO-v0")):
         e = envs.make(ref_id)
         assert type(e) is type(envs.make(name))
         assert e.unwrapped is e and e.action_space.shape == (e.dm_act,) and e.observation_space.shape == (e.dm_state,)

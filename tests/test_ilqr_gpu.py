@@ -9,7 +9,7 @@ from tests.util import TOL, assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
-ENVS = ["pendulum", "cartpole", "double_cartpole", "quadrotor", "lqr"]
+ENVS = ["pendulum", "cartpole", "double_cartpole", "quadrotor", "lqr", "double_pendulum"]
 
 
 def _pair(name, **kw):
@@ -25,7 +25,7 @@ def _pair(name, **kw):
 
 
 def _rand_state(name, rng, N):
-    n = {"pendulum": 2, "cartpole": 4, "double_cartpole": 6, "quadrotor": 12, "lqr": 2}[name]
+    n = {"pendulum": 2, "cartpole": 4, "double_cartpole": 6, "quadrotor": 12, "lqr": 2, "double_pendulum": 4}[name]
     x = rng.standard_normal((N, n))
     if name == "quadrotor":
         x[:, 3:6] *= 0.3  # keep away from the Euler singularity
@@ -34,7 +34,7 @@ def _rand_state(name, rng, N):
 
 def test_env_struct_matches_oracle_struct():
     for name in ENVS:
-        for kw in ({}, dict(dt=0.05, uw=[1e-2] if name != "quadrotor" else [1e-2] * 4, slew_rate=True, periodic=True)):
+        for kw in ({}, dict(dt=0.05, uw=[1e-2] * {"quadrotor": 4, "double_pendulum": 2}.get(name, 1), slew_rate=True, periodic=True)):
             pe, oe = _pair(name, **kw)
             assert bytes(pe.struct()) == bytes(oe), name
 
@@ -183,6 +183,7 @@ def _solve_pair(oracle, name, N, T, iters, seed=1337, scale=1e-2, gains_layout=N
     ("double_cartpole", 50, 3, dict(dt=0.01, uw=[1e-5])),
     ("quadrotor", 40, 3, dict(dt=0.02)),                      # gains group defaults to PROBLEM_MAJOR (dx > 6)
     ("lqr", 60, 5, dict()),
+    ("double_pendulum", 50, 4, dict(dt=0.02)),                # a further env model, dx = 4, du = 2
     ("cartpole", 40, 4, dict(dt=0.02, uw=[1e-5], gains_layout=0)),          # forced PROBLEM_MAJOR gains group
     ("double_cartpole", 30, 3, dict(dt=0.01, uw=[1e-5], gains_layout=0)),
     ("quadrotor", 30, 2, dict(dt=0.02, gains_layout=1)),                    # forced PROBLEM_MINOR

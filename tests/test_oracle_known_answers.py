@@ -178,7 +178,7 @@ def test_is_sympd_rule(oracle, mirror):
 
 
 ENVS = [("pendulum", dict(dt=0.05)), ("cartpole", dict(dt=0.02)), ("double_cartpole", dict()), ("quadrotor", dict()),
-        ("lqr", dict())]
+        ("lqr", dict()), ("double_pendulum", dict(dt=0.02))]
 
 
 @pytest.mark.parametrize("name,kw", ENVS)

@@ -13,9 +13,10 @@ SO_PATH = os.path.join(_HERE, "libtrajopt_amd.so")
 LAYOUT_PROBLEM_MAJOR = 0
 LAYOUT_PROBLEM_MINOR = 1
 MAX_ALPHAS = 16
+ABI_VERSION = 2          # include/trajopt_amd.h::TRAJOPT_ABI_VERSION
 MAX_STATE, MAX_ACT = 12, 4
 
-ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR = 1, 2, 3, 4, 5
+ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR, ENV_DOUBLE_PENDULUM = 1, 2, 3, 4, 5, 6
 
 
 class TrajoptError(RuntimeError):

@@ -4,13 +4,15 @@
 //   cartpole         /root/reference/trajopt/envs/cartpole/cartpole.py:62-97, :112-127
 //   double cartpole  /root/reference/trajopt/envs/double_cartpole/double_cartpole.py:61-155, :170-187
 //   LQR (affine LTI) /root/reference/trajopt/envs/lqr/lqr_v0.py:50-66, :89-94
+//   double pendulum  /root/reference/trajopt/envs/double_pendulum/double_pendulum.py:61-125, :140-154
 //   quadrotor        build-defined 12-state rigid body (no counterpart in the reference)
 //
 // Everything is a template over the scalar type so the same vector field serves the rollout (double)
 // and the quadratisation (Dual<K>: forward-mode AD carrying K tangent directions, which reproduces
 // autograd's jacobian() of the discrete RK4+clip map to round-off; objects.py:108-117).
 // phys[] per model:  pendulum {g, m, l, k}; cartpole {g, Mc, Mp, l, fr};
-//                    double cartpole {g, Mc, Mp1, Mp2, L1, L2}; quadrotor {g, mass, L, Ixx, Iyy, Izz, kM}.
+//                    double cartpole {g, Mc, Mp1, Mp2, L1, L2}; quadrotor {g, mass, L, Ixx, Iyy, Izz, kM};
+//                    double pendulum {g, m1, m2, l1, l2, k1, k2}.
 #pragma once
 #include "common.h"
 
@@ -210,6 +212,36 @@ template <> struct Model<TRAJOPT_ENV_DOUBLE_CARTPOLE> {
         const X y1 = (b1 - a23 * y2) * i22;
         const X y0 = (r0 - m12 * y1 - m13 * y2) * i11;
         dx[0] = x[3]; dx[1] = dth1; dx[2] = dth2; dx[3] = y0; dx[4] = y1; dx[5] = y2;
+    }
+};
+
+template <> struct Model<TRAJOPT_ENV_DOUBLE_PENDULUM> {
+    static constexpr int N = 4, M = 2;
+    template <class X> static __device__ __forceinline__ void f(const trajopt_env_t& e, const X (&x)[N], const X (&u)[M], X (&dx)[N]) {
+        // double_pendulum.py:66-113 (two torque-driven links, "PolicySearchToolbox" model; th1 = 0 is upright)
+        const double g = e.phys[0], m1 = e.phys[1], m2 = e.phys[2], l1 = e.phys[3], l2 = e.phys[4], k1 = e.phys[5],
+                     k2 = e.phys[6];
+        const double I1 = m1 * (l1 * l1 + 1e-4) / 3.0, I2 = m2 * (l2 * l2 + 1e-4) / 3.0;
+        const double l1c = 0.5 * l1, l2c = 0.5 * l2;
+        const double a = l1 * l2c * m2;                       // coupling
+        const double h22 = I2 + l2c * l2c * m2;               // constant entries
+        const double h11c = I1 + I2 + l1c * l1c * m1 + l1 * l1 * m2 + l2c * l2c * m2;
+        const double g1 = g * (l1c * m1 + l1 * m2), g2 = g * l2c * m2;
+        X s1, c1, s2, c2;
+        sincos_g(x[0] + M_PI, s1, c1);
+        sincos_g(x[1], s2, c2);
+        const X dth1 = x[2], dth2 = x[3];
+        const X h11 = h11c + (2.0 * a) * c2;
+        const X h12 = h22 + a * c2;                            // = h21
+        const X gsum = g2 * (c2 * s1 + c1 * s2);               // g l2c m2 (c2 s1 + c1 s2)
+        const X b1 = g1 * s1 + gsum - a * s2 * (2.0 * dth1 * dth2 + dth2 * dth2);
+        const X b2 = gsum + a * s2 * (dth1 * dth1);
+        const X r1 = (u[0] - k1 * dth1) - b1, r2 = (u[1] - k2 * dth2) - b2;
+        const X idet = recip_pos(h11 * h22 - h12 * h12);       // det of a mass matrix: positive
+        dx[0] = dth1;
+        dx[1] = dth2;
+        dx[2] = (h22 * r1 - h12 * r2) * idet;
+        dx[3] = (h11 * r2 - h12 * r1) * idet;
     }
 };
 

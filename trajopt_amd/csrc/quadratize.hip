@@ -78,20 +78,19 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
         u[j] = (j < m && t < T) ? usrc[qi<MINOR>((size_t)m * t + j, Em, p, NP)] : 0.0;
         ul[j] = (j < m && t >= 1) ? usrc[qi<MINOR>((size_t)m * (t - 1) + j, Em, p, NP)] : 0.0;
     }
-    if (commit) {
-        // Every load of the commit is issued before its first store: the arrays are not __restrict__, so a store
-        // followed by a load is kept in program order and each such pair costs one more full memory round trip per
-        // wave (the fused commit doubled the kernel's time that way).
-        double cK[N * M], ckff[M];
-        const size_t Enm_ = (size_t)n * m * T;
-        if (t < T) {
+    // Fused commit: its loads are issued here, with the trajectory loads; its stores come last (after the expansion
+    // has been computed and stored), so that nothing of the commit sits between the loads and the arithmetic.
+    double cK[N * M], ckff[M];
+    const size_t Enm_ = (size_t)n * m * T;
+    if (commit && t < T) {
 #pragma unroll
-            for (int j = 0; j < M; ++j)
-                if (j < m) ckff[j] = a.cand_kff[qi<OMINOR>((size_t)m * t + j, Em, p, NP)];
+        for (int j = 0; j < M; ++j)
+            if (j < m) ckff[j] = a.cand_kff[qi<OMINOR>((size_t)m * t + j, Em, p, NP)];
 #pragma unroll
-            for (int k = 0; k < N * M; ++k)
-                if (k < n * m) cK[k] = a.cand_K[qi<OMINOR>((size_t)n * m * t + k, Enm_, p, NP)];
-        }
+        for (int k = 0; k < N * M; ++k)
+            if (k < n * m) cK[k] = a.cand_K[qi<OMINOR>((size_t)n * m * t + k, Enm_, p, NP)];
+    }
+    auto commit_stores = [&]() {
 #pragma unroll
         for (int i = 0; i < N; ++i)
             if (i < n) a.c_xref[qi<MINOR>((size_t)n * t + i, En1, p, NP)] = x[i];
@@ -106,8 +105,11 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
             for (int k = 0; k < N * M; ++k)
                 if (k < n * m) a.c_K[qi<OMINOR>((size_t)n * m * t + k, Enm_, p, NP)] = cK[k];
         }
+    };
+    if (!live) {
+        if (commit) commit_stores();
+        return;
     }
-    if (!live) return;
 
     if (t < T) {  // dynamics Jacobian columns of this chunk
         const int k0 = chunk * KC;
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
                 }
             }
     }
+    if (commit) commit_stores();
 }
 
 // Riccati convention fix-up (riccati/objects.py:60-65,107-108), one thread per (problem, step):
@@ -241,6 +244,7 @@ template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_PENDULUM>> { static constexpr int
 template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_CARTPOLE>> { static constexpr int KC = 5; };
 template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_DOUBLE_CARTPOLE>> { static constexpr int KC = 4; };
 template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_QUADROTOR>> { static constexpr int KC = 4; };
+template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_DOUBLE_PENDULUM>> { static constexpr int KC = 3; };
 
 // the Riccati fix-up kernel reads A, B, C.. with the input layout flag: mixed layouts are an iLQR-driver feature
 static inline bool a_convention_needs_same_layout(int convention, int layout, int out_layout) {

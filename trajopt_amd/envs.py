@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_PENDULUM, ENV_QUADROTOR, MAX_ACT, MAX_STATE,
+from ._lib import (ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_DOUBLE_PENDULUM, ENV_LQR, ENV_PENDULUM, ENV_QUADROTOR, MAX_ACT, MAX_STATE,
                    EnvStruct)
 
 
@@ -195,6 +195,22 @@ class DoubleCartpole(Env):
         super().__init__()
 
 
+class DoublePendulum(Env):
+    """/root/reference/trajopt/envs/double_pendulum/double_pendulum.py:15-172 (a further env model
+    behind the same interface; two torque-driven links, dx = 4, du = 2)."""
+    model, angles = ENV_DOUBLE_PENDULUM, (0,)
+    phys = (9.81, 1., 1., 1., 1., 0.025, 0.025)  # g, m1, m2, l1, l2, k1, k2  (double_pendulum.py:66-70)
+
+    def __init__(self):
+        self.dm_state, self.dm_act, self.dt = 4, 2, 0.01
+        self.sigma = 1e-8 * np.eye(4)
+        self.g, self.gw = np.zeros(4), np.array([1e4, 1e4, 1e0, 1e0])
+        self.xmax = np.full(4, np.inf)
+        self.uw, self.umax = 1e-5 * np.ones(2), 10. * np.ones(2)
+        self.x0, self.sigma0 = np.array([np.pi, 0., 0., 0.]), 1e-4 * np.eye(4)
+        super().__init__()
+
+
 class LQRv0(Env):
     """/root/reference/trajopt/envs/lqr/lqr_v0.py:8-114: xn = A x + B clip(u) + c, cost scaled by dt.
     A, B, c, g, gw, uw may be replaced (any dx <= 12, du <= 4) for the time-invariant LQ known-answer cases."""
@@ -244,7 +260,7 @@ class Quadrotor(Env):
 _REGISTRY = {
     # the reference's gym ids (/root/reference/trajopt/__init__.py:3-97) for the envs in scope
     "Pendulum-TO-v0": Pendulum, "Cartpole-TO-v0": Cartpole, "DoubleCartpole-TO-v0": DoubleCartpole,
-    "LQR-TO-v0": LQRv0,
+    "LQR-TO-v0": LQRv0, "DoublePendulum-TO-v0": DoublePendulum, "double_pendulum": DoublePendulum,
     "pendulum": Pendulum, "cartpole": Cartpole, "double_cartpole": DoubleCartpole, "lqr": LQRv0,
     "quadrotor": Quadrotor, "Quadrotor-TO-v0": Quadrotor,
 }
