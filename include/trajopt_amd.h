@@ -143,6 +143,42 @@ int trajopt_riccati_backward_pass_batched(const double* Cxx, const double* cx, c
                                           double* kff, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * SURVEY 8f.2 (first "next" row after the iLQR path).  Max-entropy (GPS) backward pass:
+ * replaces trajopt.gps.core.backward_pass, /root/reference/trajopt/gps/src/util.cpp:272-374 (called from
+ * gps/mbgps.py:250-260): Q.. = -(C.. + F'V'F)/alpha with the affine dynamics term c, the process noise sigma_dyn
+ * (n,n,T), the constant c0 (T+1) and the per-step temperature alpha (T); outputs as the reference's tuple
+ * Qxx Qux Quu qx qu q0 V v v0 K kff sigma_ctl.  Shapes with a kernel: trajopt_gps_backward_supported().
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct trajopt_gps_backward_io {
+    const double* Cxx; const double* cx; const double* Cuu; const double* cu; const double* Cxu; const double* c0;
+    const double* A; const double* B; const double* c; const double* sigma_dyn;
+    const double* alpha;   /* (T,) per problem */
+    /* optional outputs (NULL skips the store) */
+    double* Qxx; double* Qux; double* Quu; double* qx; double* qu; double* q0;
+    /* required outputs */
+    double* V; double* v; double* v0; double* K; double* kff; double* sigma_ctl;
+    int32_t* diverge;      /* [nb_problems]: -1 = the sweep completed, else the time index it stopped at */
+    int32_t* status;       /* [nb_problems], may be NULL: 0 ok, 1 Quu positive definite (util.cpp:333-336),
+                              2 Quu singular (Armadillo's inv() throws) */
+} trajopt_gps_backward_io_t;
+
+int trajopt_gps_backward_supported(int dm_state, int dm_act);
+
+/* device arrays, PROBLEM_MINOR (or one problem in either layout) */
+int trajopt_gps_backward_pass_batched(const trajopt_gps_backward_io_t* io, int dm_state, int dm_act, int nb_steps,
+                                      int64_t nb_problems, int layout, void* stream);
+
+/* host arrays in the reference's layout; *diverge as the reference's int (0 = none) */
+int trajopt_gps_backward_pass_host(const double* Cxx_host, const double* cx_host, const double* Cuu_host,
+                                   const double* cu_host, const double* Cxu_host, const double* c0_host,
+                                   const double* A_host, const double* B_host, const double* c_host,
+                                   const double* sigma_dyn_host, const double* alpha_host, int dm_state, int dm_act,
+                                   int nb_steps, double* Qxx_host, double* Qux_host, double* Quu_host, double* qx_host,
+                                   double* qu_host, double* q0_host, double* V_host, double* v_host, double* v0_host,
+                                   double* K_host, double* kff_host, double* sigma_ctl_host, int* diverge,
+                                   int* status);
+
+/* ------------------------------------------------------------------------------------------------
  * A8.  Env model evaluated on the device: xn = env.dynamics(x, u), c = env.cost(x, u, u_last, a)
  * (e.g. cartpole.py:62-97,112-127).  x (n, N), u (m, N), PROBLEM_MINOR or MAJOR per `layout`.
  * Either output may be NULL.

@@ -92,6 +92,36 @@ def riccati_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, c, n, m, T, literal_eleme
     return K, kff, V, v
 
 
+def gps_backward_pass(Cxx, cx, Cuu, cu, Cxu, c0, A, B, c, sigma_dyn, alpha, n, m, T):
+    """gps/src/util.cpp:272-374 with NumPy's own inv / det.  -> dict of the 12 arrays + diverge."""
+    o = dict(Qxx=np.zeros((n, n, T)), Qux=np.zeros((m, n, T)), Quu=np.zeros((m, m, T)), qx=np.zeros((n, T)),
+             qu=np.zeros((m, T)), q0=np.zeros(T), V=np.zeros((n, n, T + 1)), v=np.zeros((n, T + 1)),
+             v0=np.zeros(T + 1), K=np.zeros((m, n, T)), kff=np.zeros((m, T)), sigma_ctl=np.zeros((m, m, T)), diverge=0)
+    o["V"][..., T], o["v"][..., T], o["v0"][T] = Cxx[..., T], cx[..., T], c0[T]
+    for i in range(T - 1, -1, -1):
+        a, b, ci, Vn, vn, al = A[..., i], B[..., i], c[..., i], o["V"][..., i + 1], o["v"][..., i + 1], alpha[i]
+        Qxx = -(Cxx[..., i] + a.T @ Vn @ a) / al
+        Quu = -(Cuu[..., i] + b.T @ Vn @ b) / al
+        Qux = -(Cxu[..., i] + a.T @ Vn @ b).T / al
+        qu = -(cu[..., i] + 2.0 * b.T @ Vn @ ci + b.T @ vn) / al
+        qx = -(cx[..., i] + 2.0 * a.T @ Vn @ ci + a.T @ vn) / al
+        q0 = -(c0[i] + o["v0"][i + 1] + ci @ Vn @ ci + np.trace(Vn @ sigma_dyn[..., i]) + vn @ ci) / al
+        o["Qxx"][..., i], o["Quu"][..., i], o["Qux"][..., i] = Qxx, Quu, Qux
+        o["qu"][..., i], o["qx"][..., i], o["q0"][i] = qu, qx, q0
+        if np.allclose(Quu, Quu.T, rtol=0, atol=1e-12 * np.abs(Quu).max()) and np.all(np.linalg.eigvalsh(Quu) > 0):
+            o["diverge"] = i
+            break
+        Qi = np.linalg.inv(Quu)
+        K, kff = -Qi @ Qux, -0.5 * Qi @ qu
+        sg = -0.5 * Qi
+        o["K"][..., i], o["kff"][..., i], o["sigma_ctl"][..., i] = K, kff, 0.5 * (sg.T + sg)
+        Vi = -al * (Qxx + Qux.T @ K)
+        o["V"][..., i] = 0.5 * (Vi + Vi.T)
+        o["v"][..., i] = -al * (qx + 2.0 * Qux.T @ kff)
+        o["v0"][i] = -al * (0.5 * qu @ kff + q0 + 0.5 * (m * np.log(2.0 * np.pi) - np.log(np.linalg.det(-2.0 * Quu))))
+    return o
+
+
 # ---- env models (work on float or complex inputs) ----------------------------------------------------
 def _clip(x, lim):
     """np.clip(x, -lim, lim) on the real part; the imaginary part follows autograd's mask."""

@@ -50,6 +50,19 @@ int oracle_riccati_backward_pass_ld(const double* Cxx, const double* cx, const d
                                               K, kff);
 }
 
+// gps/src/util.cpp:272-374; outputs zero-filled by the caller
+int oracle_gps_backward_pass(const double* Cxx, const double* cx, const double* Cuu, const double* cu,
+                             const double* Cxu, const double* c0, const double* A, const double* B, const double* c,
+                             const double* sigma_dyn, const double* alpha, int n, int m, int T, int long_double,
+                             double* Qxx, double* Qux, double* Quu, double* qx, double* qu, double* q0, double* V,
+                             double* v, double* v0, double* K, double* kff, double* sigma_ctl, int* failed) {
+    if (long_double)
+        return gps_backward_pass<long double>(Cxx, cx, Cuu, cu, Cxu, c0, A, B, c, sigma_dyn, alpha, n, m, T, Qxx, Qux,
+                                              Quu, qx, qu, q0, V, v, v0, K, kff, sigma_ctl, failed);
+    return gps_backward_pass<double>(Cxx, cx, Cuu, cu, Cxu, c0, A, B, c, sigma_dyn, alpha, n, m, T, Qxx, Qux, Quu, qx,
+                                     qu, q0, V, v, v0, K, kff, sigma_ctl, failed);
+}
+
 void oracle_env_dynamics(const trajopt_env_t* e, const double* x, const double* u, double* xn) {
     dynamics<double>(*e, x, u, xn);
 }

@@ -161,6 +161,30 @@ def riccati_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, c, dm_state, dm_act, nb_s
     return K, kff, V, v
 
 
+# ---- 8f.2 ---------------------------------------------------------------------------------------
+GPS_OUT = ("Qxx", "Qux", "Quu", "qx", "qu", "q0", "V", "v", "v0", "K", "kff", "sigma_ctl")
+
+
+def gps_backward_pass(Cxx, cx, Cuu, cu, Cxu, c0, A, B, c, sigma_dyn, alpha, dm_state, dm_act, nb_steps,
+                      long_double=False):
+    """gps/src/util.cpp:272-374.  Returns (the reference's 13-tuple, failed)."""
+    n, m, T = dm_state, dm_act, nb_steps
+    Cxx, cx, Cuu, cu, Cxu, c0, A, B, c, sigma_dyn, alpha = map(_f, (Cxx, cx, Cuu, cu, Cxu, c0, A, B, c, sigma_dyn,
+                                                                      alpha))
+    assert c0.shape == (T + 1,) and c.shape == (n, T) and sigma_dyn.shape == (n, n, T) and alpha.shape == (T,)
+    z = lambda *s: np.zeros(s, order="F")
+    Qxx, Qux, Quu, qx, qu, q0 = z(n, n, T), z(m, n, T), z(m, m, T), z(n, T), z(m, T), z(T)
+    V, v, v0, K, kff, sg = z(n, n, T + 1), z(n, T + 1), z(T + 1), z(m, n, T), z(m, T), z(m, m, T)
+    failed = C.c_int(0)
+    rc = lib().oracle_gps_backward_pass(_p(Cxx), _p(cx), _p(Cuu), _p(cu), _p(Cxu), _p(c0), _p(A), _p(B), _p(c),
+                                        _p(sigma_dyn), _p(alpha), n, m, T, int(long_double), _p(Qxx), _p(Qux),
+                                        _p(Quu), _p(qx), _p(qu), _p(q0), _p(V), _p(v), _p(v0), _p(K), _p(kff), _p(sg),
+                                        C.byref(failed))
+    if rc < 0:
+        raise np.linalg.LinAlgError("singular Quu at step %d" % (-rc - 1))
+    return (Qxx, Qux, Quu, qx, qu, q0, V, v, v0, K, kff, sg, int(rc)), bool(failed.value)
+
+
 # ---- A8 / A3 / A4 / A5 / A10 ----------------------------------------------------------------------
 def env_dynamics(e, x, u):
     x, u = _f(x), _f(np.atleast_1d(u))

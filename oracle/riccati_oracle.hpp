@@ -310,4 +310,112 @@ int riccati_backward_pass(const double* Cxx, const double* cx, const double* Cuu
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// the max-entropy (GPS) backward pass, /root/reference/trajopt/gps/src/util.cpp:272-374.
+// Same recursion skeleton as A1/A9 with the affine dynamics term c, the process noise sigma_dyn, the constant c0
+// and a per-step temperature alpha:  Q.. = -(C.. + F'V'F)/alpha  (negative definite Quu expected; the reference
+// flags a step whose Quu passes is_sympd(), :329-332), K = -Quu^-1 Qux, kff = -1/2 Quu^-1 qu,
+// sigma_ctl = sym(-1/2 Quu^-1), V = sym(-alpha (Qxx + Qux'K)), v = -alpha (qx + 2 Qux'kff),
+// v0 = -alpha (1/2 qu'kff + q0 + 1/2 (m log 2pi - log det(-2 Quu))).
+// Output buffers must be zero-filled by the caller.  Returns the reference's `_diverge` (0 = none, else the failing
+// time index); *failed gets the unambiguous flag; a singular Quu (Armadillo's inv() throws) returns -(t + 1).
+// ---------------------------------------------------------------------------------------------
+template <class S>
+static S det_gj(const M<S>& X) {
+    const int n = X.r;
+    M<S> A = X;
+    S d = 1;
+    for (int k = 0; k < n; ++k) {
+        int piv = k;
+        for (int i = k + 1; i < n; ++i)
+            if (std::fabs(A(i, k)) > std::fabs(A(piv, k))) piv = i;
+        if (A(piv, k) == S(0)) return S(0);
+        if (piv != k) {
+            for (int j = 0; j < n; ++j) std::swap(A(k, j), A(piv, j));
+            d = -d;
+        }
+        d *= A(k, k);
+        for (int i = k + 1; i < n; ++i) {
+            S f = A(i, k) / A(k, k);
+            for (int j = k; j < n; ++j) A(i, j) -= f * A(k, j);
+        }
+    }
+    return d;
+}
+
+template <class S>
+int gps_backward_pass(const double* Cxx, const double* cx, const double* Cuu, const double* cu, const double* Cxu,
+                      const double* c0, const double* A, const double* B, const double* c, const double* sigma_dyn,
+                      const double* alpha, int n, int m, int T, double* Qxx, double* Qux, double* Quu, double* qx,
+                      double* qu, double* q0, double* V, double* v, double* v0, double* K, double* kff,
+                      double* sigma_ctl, int* failed) {
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
+    *failed = 0;
+    M<S> Vn = load<S>(Cxx + nn * T, n, n);          // :318
+    M<S> vn = load<S>(cx + (size_t)n * T, n, 1);    // :319
+    S v0n = (S)c0[T];                               // :320
+    store(V + nn * T, Vn);
+    store(v + (size_t)n * T, vn);
+    v0[T] = (double)v0n;
+    for (int i = T - 1; i >= 0; --i) {  // :322
+        const S al = (S)alpha[i];
+        M<S> Ai = load<S>(A + nn * i, n, n), Bi = load<S>(B + nm * i, n, m), ci = load<S>(c + (size_t)n * i, n, 1);
+        M<S> At = tr(Ai), Bt = tr(Bi);
+        M<S> Qxx_i = scale(add(load<S>(Cxx + nn * i, n, n), mul3(At, Vn, Ai)), S(-1) / al);          // :324
+        M<S> Quu_i = scale(add(load<S>(Cuu + mm * i, m, m), mul3(Bt, Vn, Bi)), S(-1) / al);          // :325
+        M<S> Qux_i = scale(tr(add(load<S>(Cxu + nm * i, n, m), mul3(At, Vn, Bi))), S(-1) / al);      // :326
+        M<S> Vc = mul(Vn, ci);
+        M<S> qu_i = scale(add(add(load<S>(cu + (size_t)m * i, m, 1), scale(mul(Bt, Vc), S(2))), mul(Bt, vn)),
+                          S(-1) / al);                                                                 // :328
+        M<S> qx_i = scale(add(add(load<S>(cx + (size_t)n * i, n, 1), scale(mul(At, Vc), S(2))), mul(At, vn)),
+                          S(-1) / al);                                                                 // :329
+        S trVS = 0;  // trace(V' sigma_dyn)
+        {
+            M<S> Sg = load<S>(sigma_dyn + nn * i, n, n);
+            for (int r = 0; r < n; ++r)
+                for (int k = 0; k < n; ++k) trVS += Vn(r, k) * Sg(k, r);
+        }
+        S cVc = 0, vc = 0;
+        for (int r = 0; r < n; ++r) {
+            cVc += ci(r, 0) * Vc(r, 0);
+            vc += vn(r, 0) * ci(r, 0);
+        }
+        const S q0_i = -((S)c0[i] + v0n + cVc + trVS + vc) / al;                                       // :330-331
+        store(Qxx + nn * i, Qxx_i);
+        store(Quu + mm * i, Quu_i);
+        store(Qux + nm * i, Qux_i);
+        store(qu + (size_t)m * i, qu_i);
+        store(qx + (size_t)n * i, qx_i);
+        q0[i] = (double)q0_i;
+        if (is_sympd(Quu_i)) {  // :333-336
+            *failed = 1;
+            return i;
+        }
+        M<S> Quu_inv, I(m, m);
+        for (int k = 0; k < m; ++k) I(k, k) = S(1);
+        if (!gj_solve(Quu_i, I, Quu_inv)) return -(i + 1);  // :338 inv() throws
+        M<S> K_i = scale(mul(Quu_inv, Qux_i), S(-1));        // :339
+        M<S> kff_i = scale(mul(Quu_inv, qu_i), S(-0.5));     // :340
+        M<S> sg = scale(Quu_inv, S(-0.5));                   // :342
+        sg = scale(add(tr(sg), sg), S(0.5));                 // :343
+        M<S> V_i = scale(add(Qxx_i, mul(tr(Qux_i), K_i)), -al);          // :348
+        V_i = scale(add(V_i, tr(V_i)), S(0.5));                          // :349
+        M<S> v_i = scale(add(qx_i, scale(mul(tr(Qux_i), kff_i), S(2))), -al);   // :351
+        S qk = 0;
+        for (int k = 0; k < m; ++k) qk += qu_i(k, 0) * kff_i(k, 0);
+        const S ldet = std::log(det_gj(scale(Quu_i, S(-2))));
+        const S v0_i = -al * (S(0.5) * qk + q0_i + S(0.5) * (S(m) * std::log(S(2) * (S)M_PI) - ldet));   // :352-353
+        store(K + nm * i, K_i);
+        store(kff + (size_t)m * i, kff_i);
+        store(sigma_ctl + mm * i, sg);
+        store(V + nn * i, V_i);
+        store(v + (size_t)n * i, v_i);
+        v0[i] = (double)v0_i;
+        Vn = V_i;
+        vn = v_i;
+        v0n = v0_i;
+    }
+    return 0;
+}
+
 }  // namespace oracle

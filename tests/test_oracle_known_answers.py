@@ -236,3 +236,51 @@ def test_ilqr_driver_vs_mirror(oracle, mirror, name, T, iters, kw):
     assert r["lmbda"] == pytest.approx(mr["lmbda"], rel=1e-12)
     assert_close(r["xref"], mr["xref"], "xref", tol=1e-7)
     assert r["trace"][-1] < r["trace"][0]
+
+
+# ---- the max-entropy (GPS) backward pass, gps/src/util.cpp:272-374 -------------------------------
+GPS_ARGS = ("Cxx", "cx", "Cuu", "cu", "Cxu", "c0", "A", "B", "c", "sigma_dyn", "alpha")
+
+
+@pytest.mark.parametrize("n,m,T", [(2, 1, 100), (4, 1, 120), (4, 2, 60), (6, 1, 80), (12, 4, 30)])
+def test_gps_oracle_vs_mirror_vs_long_double(oracle, mirror, n, m, T):
+    q = S.problem(S.gps_inputs(n, m, T, 1, seed=200 + n), 0)
+    args = [q[k] for k in GPS_ARGS]
+    o, f = oracle.gps_backward_pass(*args, n, m, T)
+    ld, _ = oracle.gps_backward_pass(*args, n, m, T, long_double=True)
+    mi = mirror.gps_backward_pass(*args, n, m, T)
+    assert not f and o[12] == 0 and mi["diverge"] == 0
+    for k, a, b in zip(oracle.GPS_OUT, o[:12], ld[:12]):
+        assert_close(a, b, "ld " + k, tol=1e-10)
+        assert_close(a, mi[k], "mirror " + k, tol=1e-10)
+
+
+def test_gps_gains_do_not_depend_on_the_temperature(oracle):
+    """K = -Quu^-1 Qux and kff = -1/2 Quu^-1 qu cancel alpha: they, V and v are those of the TV-LQR sweep of the
+    same problem (riccati.py:108-124 uses the same "no 1/2" convention as util.cpp:322-351), while sigma_ctl scales
+    linearly with alpha."""
+    n, m, T = 4, 2, 50
+    q = S.problem(S.gps_inputs(n, m, T, 1, seed=77), 0)
+    args = {k: q[k] for k in GPS_ARGS}
+    a, _ = oracle.gps_backward_pass(*args.values(), n, m, T)
+    args2 = dict(args, alpha=3.0 * q["alpha"])
+    b, _ = oracle.gps_backward_pass(*args2.values(), n, m, T)
+    for i in (6, 7, 9, 10):  # V, v, K, kff
+        assert_close(a[i], b[i], oracle.GPS_OUT[i], tol=1e-11)
+    assert_close(3.0 * a[11], b[11], "sigma_ctl", tol=1e-11)
+    K, kff, V, v = oracle.riccati_backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"],
+                                                q["c"], n, m, T)
+    assert_close(a[9], K, "K vs riccati", tol=1e-10)
+    assert_close(a[10], kff, "kff vs riccati", tol=1e-10)
+    assert_close(a[6], V, "V vs riccati", tol=1e-10)
+    assert_close(a[7], v, "v vs riccati", tol=1e-10)
+
+
+def test_gps_positive_definite_quu_is_the_divergence(oracle, mirror):
+    n, m, T = 2, 1, 20
+    q = S.problem(S.gps_inputs(n, m, T, 1, seed=1), 0)
+    q["Cuu"][:, :, 11] = -50.0
+    args = [q[k] for k in GPS_ARGS]
+    o, f = oracle.gps_backward_pass(*args, n, m, T)
+    assert f and o[12] == 11 and mirror.gps_backward_pass(*args, n, m, T)["diverge"] == 11
+    assert np.all(o[9][..., :11] == 0.0) and np.all(o[9][..., 12:] != 0.0)

@@ -53,6 +53,13 @@ class BackwardIO(C.Structure):
                 [("cost_gxx", C.c_double * MAX_STATE), ("cost_guu", C.c_double * MAX_ACT)])
 
 
+class GpsBackwardIO(C.Structure):
+    """include/trajopt_amd.h::trajopt_gps_backward_io_t"""
+    _fields_ = [(k, _dp) for k in
+                ("Cxx", "cx", "Cuu", "cu", "Cxu", "c0", "A", "B", "c", "sigma_dyn", "alpha",
+                 "Qxx", "Qux", "Quu", "qx", "qu", "q0", "V", "v", "v0", "K", "kff", "sigma_ctl", "diverge", "status")]
+
+
 class ILQROptions(C.Structure):
     _fields_ = [("sched", LambdaSchedule), ("tolfun", C.c_double), ("tolgrad", C.c_double),
                 ("min_imp", C.c_double), ("reg", C.c_int32), ("nb_alphas", C.c_int32),
@@ -77,6 +84,7 @@ EXPORTS = (
     "trajopt_abi_version", "trajopt_error_string", "trajopt_last_hip_error", "trajopt_device_count",
     "trajopt_ilqr_backward_pass_host", "trajopt_ilqr_backward_pass_batched",
     "trajopt_backward_supports_structured_cost",
+    "trajopt_gps_backward_supported", "trajopt_gps_backward_pass_batched", "trajopt_gps_backward_pass_host",
     "trajopt_riccati_backward_pass_host", "trajopt_riccati_backward_pass_batched",
     "trajopt_env_step_batched", "trajopt_ilqr_forward_pass_batched", "trajopt_quadratize_batched",
     "trajopt_ilqr_init_rollout", "trajopt_ilqr_iterate", "trajopt_convert_layout",

@@ -5,7 +5,7 @@ Thin plumbing over the C ABI: torch only provides device memory and the current 
 import ctypes as C
 
 from . import _lib
-from ._lib import BackwardIO, LambdaSchedule, LAYOUT_PROBLEM_MAJOR, LAYOUT_PROBLEM_MINOR, check, dptr, lib, stream_ptr
+from ._lib import BackwardIO, GpsBackwardIO, LambdaSchedule, LAYOUT_PROBLEM_MAJOR, LAYOUT_PROBLEM_MINOR, check, dptr, lib, stream_ptr
 from .layout import empty
 
 
@@ -91,4 +91,39 @@ def riccati_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, c, dm_state, dm_act, nb_s
     check(lib().trajopt_riccati_backward_pass_batched(
         dptr(Cxx), dptr(cx), dptr(Cuu), dptr(cu), dptr(Cxu), dptr(A), dptr(B), dptr(c), n, m, T, C.c_int64(N),
         int(layout), dptr(o["V"]), dptr(o["v"]), dptr(o["K"]), dptr(o["kff"]), dptr(o["status"]), stream_ptr()))
+    return o
+
+
+def gps_backward_pass(Cxx, cx, Cuu, cu, Cxu, c0, A, B, c, sigma_dyn, alpha, dm_state, dm_act, nb_steps, nb_problems,
+                      layout=LAYOUT_PROBLEM_MINOR, full=True):
+    """Max-entropy backward pass of /root/reference/trajopt/gps/src/util.cpp:272-374 for a batch.
+
+    Device tensors in PROBLEM_MINOR; alpha is (N, T) in that layout (one temperature per step and problem, as
+    mbgps.py's pass_alpha_as_vector hands over).  Returns K, kff, sigma_ctl, V, v, v0, diverge (-1 = completed),
+    status, and Qxx ... q0 when full=True.
+    """
+    import torch
+    _lib.require_gpu()
+    n, m, T, N = dm_state, dm_act, nb_steps, nb_problems
+    for t, cnt, nm in ((Cxx, n * n * (T + 1), "Cxx"), (cx, n * (T + 1), "cx"), (Cuu, m * m * (T + 1), "Cuu"),
+                       (cu, m * (T + 1), "cu"), (Cxu, n * m * (T + 1), "Cxu"), (c0, T + 1, "c0"), (A, n * n * T, "A"),
+                       (B, n * m * T, "B"), (c, n * T, "c"), (sigma_dyn, n * n * T, "sigma_dyn"), (alpha, T, "alpha")):
+        _chk(t, cnt * N, nm)
+    dev = A.device
+    o = dict(K=empty((N, m, n, T), layout, dev, zero=True), kff=empty((N, m, T), layout, dev, zero=True),
+             sigma_ctl=empty((N, m, m, T), layout, dev, zero=True), V=empty((N, n, n, T + 1), layout, dev, zero=True),
+             v=empty((N, n, T + 1), layout, dev, zero=True), v0=empty((N, T + 1), layout, dev, zero=True),
+             diverge=torch.empty(N, dtype=torch.int32, device=dev), status=torch.empty(N, dtype=torch.int32, device=dev))
+    if full:
+        o.update(Qxx=empty((N, n, n, T), layout, dev, zero=True), Qux=empty((N, m, n, T), layout, dev, zero=True),
+                 Quu=empty((N, m, m, T), layout, dev, zero=True), qx=empty((N, n, T), layout, dev, zero=True),
+                 qu=empty((N, m, T), layout, dev, zero=True), q0=empty((N, T), layout, dev, zero=True))
+    io = GpsBackwardIO()
+    for k, t in (("Cxx", Cxx), ("cx", cx), ("Cuu", Cuu), ("cu", cu), ("Cxu", Cxu), ("c0", c0), ("A", A), ("B", B),
+                 ("c", c), ("sigma_dyn", sigma_dyn), ("alpha", alpha)):
+        setattr(io, k, dptr(t))
+    for k in ("Qxx", "Qux", "Quu", "qx", "qu", "q0", "V", "v", "v0", "K", "kff", "sigma_ctl"):
+        setattr(io, k, dptr(o.get(k)))
+    io.diverge, io.status = dptr(o["diverge"]), dptr(o["status"])
+    check(lib().trajopt_gps_backward_pass_batched(C.byref(io), n, m, T, C.c_int64(N), int(layout), stream_ptr()))
     return o

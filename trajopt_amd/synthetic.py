@@ -45,3 +45,16 @@ def backward_inputs(n, m, T, N, seed=SEED, affine=False, dt=0.01):
 def problem(stack, p):
     """Reference-layout (Fortran-ordered) arrays of problem p."""
     return {k: np.asfortranarray(a[p]) for k, a in stack.items()}
+
+
+def gps_inputs(n, m, T, N, seed=SEED):
+    """Inputs of the max-entropy backward pass (gps/src/util.cpp:272): backward_inputs(affine=True) plus
+    c0 ~ N(0,1) (N, T+1), sigma_dyn = 1e-4 (R^T R / n + I) (N, n, n, T), alpha ~ U[0.5, 50] (N, T)."""
+    out = backward_inputs(n, m, T, N, seed=seed, affine=True)
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    out["c0"] = rng.standard_normal((N, T + 1))
+    R = rng.standard_normal((N, T, n, n))
+    S = 1e-4 * (np.einsum("ptki,ptkj->ptij", R, R) / n + np.eye(n)[None, None])
+    out["sigma_dyn"] = np.ascontiguousarray(S).transpose(0, 3, 2, 1)
+    out["alpha"] = rng.uniform(0.5, 50.0, size=(N, T))
+    return out
