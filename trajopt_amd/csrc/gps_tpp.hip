@@ -22,8 +22,10 @@ struct GpsArgs {
 
 template <int N, int M>
 struct GpsIn {
-    double A[N * N], B[N * M], c[N], S[N * N], Cxx[N * N], Cuu[M * M], Cxu[N * M], cx[N], cu[M], c0, alpha;
+    double A[N * N], B[N * M], c[N], Cuu[M * M], Cxu[N * M], cx[N], cu[M], c0, alpha;
 };
+// sigma_dyn[t] and Cxx[t] are not part of the prefetched set: the step loads them at its top and first uses them
+// after the V'F products, which keeps two sets + V + the step temporaries inside 512 VGPRs at dx = 6.
 
 template <int R>
 __device__ __forceinline__ void gld(double (&x)[R], const double* arr, size_t E, int t, size_t NP, size_t p) {
@@ -41,8 +43,6 @@ __device__ __forceinline__ void gps_load(GpsIn<N, M>& s, const trajopt_gps_backw
     gld<N * N>(s.A, io.A, N * N, t, NP, p);
     gld<N * M>(s.B, io.B, N * M, t, NP, p);
     gld<N>(s.c, io.c, N, t, NP, p);
-    gld<N * N>(s.S, io.sigma_dyn, N * N, t, NP, p);
-    gld<N * N>(s.Cxx, io.Cxx, N * N, t, NP, p);
     gld<M * M>(s.Cuu, io.Cuu, M * M, t, NP, p);
     gld<N * M>(s.Cxu, io.Cxu, N * M, t, NP, p);
     gld<N>(s.cx, io.cx, N, t, NP, p);
@@ -83,7 +83,9 @@ __global__ __launch_bounds__(64) void gps_tpp_kernel(GpsArgs a) {
 
     auto step = [&](const GpsIn<N, M>& in, int t) -> bool {
         const double na = -1.0 / in.alpha;
-        double W[N * N], Z[N * M], Vc[N];
+        double W[N * N], Z[N * M], Vc[N], Sg[N * N], Cx[N * N];
+        gld<N * N>(Sg, io.sigma_dyn, N * N, t, NP, p);
+        gld<N * N>(Cx, io.Cxx, N * N, t, NP, p);
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(64) void gps_tpp_kernel(GpsArgs a) {
         for (int j = 0; j < N; ++j)
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                double s = in.Cxx[i + N * j];
+                double s = Cx[i + N * j];
 #pragma unroll
                 for (int k = 0; k < N; ++k) s = fma(in.A[k + N * i], W[k + N * j], s);
                 Qxx[i + N * j] = na * s;  // :324
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(64) void gps_tpp_kernel(GpsArgs a) {
         for (int i = 0; i < N; ++i) {
             s0 = fma(in.c[i], Vc[i] + v[i], s0);
 #pragma unroll
-            for (int k = 0; k < N; ++k) s0 = fma(V[i + N * k], in.S[k + N * i], s0);  // trace(V' sigma_dyn)
+            for (int k = 0; k < N; ++k) s0 = fma(V[i + N * k], Sg[k + N * i], s0);  // trace(V' sigma_dyn)
         }
         const double q0 = na * s0;
         if constexpr (FULL) {
