@@ -178,6 +178,51 @@ int trajopt_gps_backward_pass_host(const double* Cxx_host, const double* cx_host
                                    double* K_host, double* kff_host, double* sigma_ctl_host, int* diverge,
                                    int* status);
 
+/* The other functions of trajopt.gps.core, same layouts and shape set (PROBLEM_MINOR, or one problem):
+ *   forward_pass      /root/reference/trajopt/gps/src/util.cpp:195-269  (gps/mbgps.py:140-145)  Gaussian moment propagation;
+ *                     the parts of the last mu_xu / sigma_xu slices the reference leaves unset are written as zero
+ *   augment_cost      util.cpp:136-193 (mbgps.py:166-170)   cost + alpha * log-policy terms; T+1 slices, the last copied
+ *   kl_divergence     util.cpp:83-121  (mbgps.py:198-201)   per-step KL(p || q) of two linear-Gaussian controllers
+ *   quad_expectation  util.cpp:123-134 (mbgps.py:184-186)   E[x'Qx + x'q + q0] under N(mu, sigma)
+ * status[p] = 1 when a sigma_ctl is not positive definite (Armadillo's inv_sympd() throws there), else 0. */
+int trajopt_gps_forward_pass_batched(const double* mu_x0, const double* sigma_x0, const double* A, const double* B,
+                                     const double* c, const double* sigma_dyn, const double* K, const double* kff,
+                                     const double* sigma_ctl, int dm_state, int dm_act, int nb_steps,
+                                     int64_t nb_problems, int layout, double* mu_x, double* sigma_x, double* mu_u,
+                                     double* sigma_u, double* mu_xu, double* sigma_xu, void* stream);
+int trajopt_gps_augment_cost_batched(const double* Cxx, const double* cx, const double* Cuu, const double* cu,
+                                     const double* Cxu, const double* c0, const double* K, const double* kff,
+                                     const double* sigma_ctl, const double* alpha, int dm_state, int dm_act,
+                                     int nb_steps, int64_t nb_problems, int layout, double* agCxx, double* agcx,
+                                     double* agCuu, double* agcu, double* agCxu, double* agc0, int32_t* status,
+                                     void* stream);
+int trajopt_gps_kl_divergence_batched(const double* p_K, const double* p_kff, const double* p_sigma_ctl,
+                                      const double* q_K, const double* q_kff, const double* q_sigma_ctl,
+                                      const double* mu_x, const double* sigma_x, int dm_state, int dm_act,
+                                      int nb_steps, int64_t nb_problems, int layout, double* kl, int32_t* status,
+                                      void* stream);
+int trajopt_gps_quad_expectation_batched(const double* mu, const double* sigma_s, const double* Q, const double* q,
+                                         const double* q0, int dm_state, int64_t nb_problems, int layout,
+                                         double* result, void* stream);
+/* host arrays in the reference's layout, one problem */
+int trajopt_gps_forward_pass_host(const double* mu_x0_host, const double* sigma_x0_host, const double* A_host,
+                                  const double* B_host, const double* c_host, const double* sigma_dyn_host,
+                                  const double* K_host, const double* kff_host, const double* sigma_ctl_host,
+                                  int dm_state, int dm_act, int nb_steps, double* mu_x_host, double* sigma_x_host,
+                                  double* mu_u_host, double* sigma_u_host, double* mu_xu_host, double* sigma_xu_host);
+int trajopt_gps_augment_cost_host(const double* Cxx_host, const double* cx_host, const double* Cuu_host,
+                                  const double* cu_host, const double* Cxu_host, const double* c0_host,
+                                  const double* K_host, const double* kff_host, const double* sigma_ctl_host,
+                                  const double* alpha_host, int dm_state, int dm_act, int nb_steps,
+                                  double* agCxx_host, double* agcx_host, double* agCuu_host, double* agcu_host,
+                                  double* agCxu_host, double* agc0_host, int* status);
+int trajopt_gps_kl_divergence_host(const double* p_K_host, const double* p_kff_host, const double* p_sigma_ctl_host,
+                                   const double* q_K_host, const double* q_kff_host, const double* q_sigma_ctl_host,
+                                   const double* mu_x_host, const double* sigma_x_host, int dm_state, int dm_act,
+                                   int nb_steps, double* kl_host, int* status);
+int trajopt_gps_quad_expectation_host(const double* mu_host, const double* sigma_s_host, const double* Q_host,
+                                      const double* q_host, double q0, int dm_state, double* result);
+
 /* ------------------------------------------------------------------------------------------------
  * A8.  Env model evaluated on the device: xn = env.dynamics(x, u), c = env.cost(x, u, u_last, a)
  * (e.g. cartpole.py:62-97,112-127).  x (n, N), u (m, N), PROBLEM_MINOR or MAJOR per `layout`.

@@ -404,3 +404,58 @@ def ilqr_run(env, T, x0, kff_init, weighting, alphas, nb_iter, lmbda=1., dlmbda=
                 break
     return dict(xref=xref, uref=uref, K=K, kff=kff, trace=np.array(trace), last_return=last_return, lmbda=lmbda,
                 dlmbda=dlmbda, status=status)
+
+
+def gps_kl_divergence(p_K, p_kff, p_sigma, q_K, q_kff, q_sigma, mu_x, sigma_x, n, m, T):
+    """gps/src/util.cpp:83-121 with np.linalg.inv / det."""
+    kl = np.zeros(T)
+    for i in range(T):
+        lam = np.linalg.inv(q_sigma[..., i])
+        dK, dk = q_K[..., i] - p_K[..., i], p_kff[..., i] - q_kff[..., i]
+        mu = mu_x[..., i]
+        kl[i] = (0.5 * np.log(np.linalg.det(q_sigma[..., i]) / np.linalg.det(p_sigma[..., i]))
+                 + 0.5 * np.trace(lam @ p_sigma[..., i]) - 0.5 * m
+                 + 0.5 * np.trace(dK.T @ lam @ dK @ sigma_x[..., i]) + 0.5 * mu @ dK.T @ lam @ dK @ mu
+                 - mu @ dK.T @ lam @ dk + 0.5 * dk @ lam @ dk)
+    return kl
+
+
+def gps_quad_expectation(mu, sigma_s, Q, q, q0):
+    """gps/src/util.cpp:123-134."""
+    return float(mu @ Q @ mu + mu @ q + q0 + np.trace(Q @ sigma_s))
+
+
+def gps_augment_cost(Cxx, cx, Cuu, cu, Cxu, c0, K, kff, sigma_ctl, alpha, n, m, T):
+    """gps/src/util.cpp:136-193."""
+    ag = [np.array(a, dtype=float, order="F") for a in (Cxx, cx, Cuu, cu, Cxu, c0)]
+    for i in range(T):
+        lam = np.linalg.inv(sigma_ctl[..., i])
+        Ki, ki, al = K[..., i], kff[..., i], alpha[i]
+        ag[0][..., i] = Cxx[..., i] + 0.5 * al * Ki.T @ lam @ Ki
+        ag[2][..., i] = Cuu[..., i] + 0.5 * al * lam
+        ag[4][..., i] = Cxu[..., i] - 0.5 * al * Ki.T @ lam
+        ag[1][..., i] = cx[..., i] + al * Ki.T @ lam @ ki
+        ag[3][..., i] = cu[..., i] - al * lam @ ki
+        ag[5][i] = c0[i] + 0.5 * al * np.log(np.linalg.det(2.0 * np.pi * sigma_ctl[..., i])) + 0.5 * al * ki @ lam @ ki
+    return tuple(ag)
+
+
+def gps_forward_pass(mu_x0, sigma_x0, A, B, c, sigma_dyn, K, kff, sigma_ctl, n, m, T):
+    """gps/src/util.cpp:195-269 (the parts of the last mu_xu / sigma_xu slices the reference leaves unset are zero)."""
+    mu_x, sigma_x = np.zeros((n, T + 1)), np.zeros((n, n, T + 1))
+    mu_u, sigma_u = np.zeros((m, T)), np.zeros((m, m, T))
+    mu_xu, sigma_xu = np.zeros((n + m, T + 1)), np.zeros((n + m, n + m, T + 1))
+    mu_x[:, 0], sigma_x[..., 0] = mu_x0, sigma_x0
+    sym = lambda X: 0.5 * (X + X.T)
+    for i in range(T):
+        Ki, sx = K[..., i], sigma_x[..., i]
+        mu_u[:, i] = Ki @ mu_x[:, i] + kff[:, i]
+        sigma_u[..., i] = sym(sigma_ctl[..., i] + Ki @ sx @ Ki.T)
+        sigma_xu[..., i] = sym(np.block([[sx, sx @ Ki.T], [Ki @ sx, sigma_u[..., i]]]))
+        mu_xu[:, i] = np.concatenate([mu_x[:, i], mu_u[:, i]])
+        F = np.hstack([A[..., i], B[..., i]])
+        sigma_x[..., i + 1] = sym(sigma_dyn[..., i] + F @ sigma_xu[..., i] @ F.T)
+        mu_x[:, i + 1] = F @ mu_xu[:, i] + c[:, i]
+    mu_xu[:n, T] = mu_x[:, T]
+    sigma_xu[:n, :n, T] = sigma_x[..., T]
+    return mu_x, sigma_x, mu_u, sigma_u, mu_xu, sigma_xu

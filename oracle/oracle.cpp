@@ -10,6 +10,7 @@
 #include <thread>
 #include <vector>
 #include "ilqr_oracle.hpp"
+#include "gps_oracle.hpp"
 
 using namespace oracle;
 
@@ -61,6 +62,39 @@ int oracle_gps_backward_pass(const double* Cxx, const double* cx, const double* 
                                               Quu, qx, qu, q0, V, v, v0, K, kff, sigma_ctl, failed);
     return gps_backward_pass<double>(Cxx, cx, Cuu, cu, Cxu, c0, A, B, c, sigma_dyn, alpha, n, m, T, Qxx, Qux, Quu, qx,
                                      qu, q0, V, v, v0, K, kff, sigma_ctl, failed);
+}
+
+// gps/src/util.cpp:83-269
+int oracle_gps_kl_divergence(const double* pK, const double* pk, const double* pS, const double* qK, const double* qk,
+                             const double* qS, const double* mu_x, const double* sigma_x, int n, int m, int T,
+                             int long_double, double* kl) {
+    if (long_double) return gps_kl_divergence<long double>(pK, pk, pS, qK, qk, qS, mu_x, sigma_x, n, m, T, kl);
+    return gps_kl_divergence<double>(pK, pk, pS, qK, qk, qS, mu_x, sigma_x, n, m, T, kl);
+}
+double oracle_gps_quad_expectation(const double* mu, const double* sigma, const double* Q, const double* q, double q0,
+                                   int n) {
+    return gps_quad_expectation<double>(mu, sigma, Q, q, q0, n);
+}
+int oracle_gps_augment_cost(const double* Cxx, const double* cx, const double* Cuu, const double* cu, const double* Cxu,
+                            const double* c0, const double* K, const double* kff, const double* sigma_ctl,
+                            const double* alpha, int n, int m, int T, int long_double, double* agCxx, double* agcx,
+                            double* agCuu, double* agcu, double* agCxu, double* agc0) {
+    if (long_double)
+        return gps_augment_cost<long double>(Cxx, cx, Cuu, cu, Cxu, c0, K, kff, sigma_ctl, alpha, n, m, T, agCxx, agcx,
+                                             agCuu, agcu, agCxu, agc0);
+    return gps_augment_cost<double>(Cxx, cx, Cuu, cu, Cxu, c0, K, kff, sigma_ctl, alpha, n, m, T, agCxx, agcx, agCuu,
+                                    agcu, agCxu, agc0);
+}
+void oracle_gps_forward_pass(const double* mu_x0, const double* sigma_x0, const double* A, const double* B,
+                             const double* c, const double* sigma_dyn, const double* K, const double* kff,
+                             const double* sigma_ctl, int n, int m, int T, int long_double, double* mu_x,
+                             double* sigma_x, double* mu_u, double* sigma_u, double* mu_xu, double* sigma_xu) {
+    if (long_double)
+        gps_forward_pass<long double>(mu_x0, sigma_x0, A, B, c, sigma_dyn, K, kff, sigma_ctl, n, m, T, mu_x, sigma_x,
+                                      mu_u, sigma_u, mu_xu, sigma_xu);
+    else
+        gps_forward_pass<double>(mu_x0, sigma_x0, A, B, c, sigma_dyn, K, kff, sigma_ctl, n, m, T, mu_x, sigma_x, mu_u,
+                                 sigma_u, mu_xu, sigma_xu);
 }
 
 void oracle_env_dynamics(const trajopt_env_t* e, const double* x, const double* u, double* xn) {

@@ -185,6 +185,50 @@ def gps_backward_pass(Cxx, cx, Cuu, cu, Cxu, c0, A, B, c, sigma_dyn, alpha, dm_s
     return (Qxx, Qux, Quu, qx, qu, q0, V, v, v0, K, kff, sg, int(rc)), bool(failed.value)
 
 
+def gps_kl_divergence(p_K, p_kff, p_sigma_ctl, q_K, q_kff, q_sigma_ctl, mu_x, sigma_x, dm_state, dm_act, nb_steps,
+                      long_double=False):
+    """gps/src/util.cpp:83-121 -> kl (T,)."""
+    n, m, T = dm_state, dm_act, nb_steps
+    a = list(map(_f, (p_K, p_kff, p_sigma_ctl, q_K, q_kff, q_sigma_ctl, mu_x, sigma_x)))
+    kl = np.zeros(T)
+    rc = lib().oracle_gps_kl_divergence(*map(_p, a), n, m, T, int(long_double), _p(kl))
+    if rc:
+        raise np.linalg.LinAlgError("inv_sympd(): q_sigma_ctl not positive definite at step %d" % (rc - 1))
+    return kl
+
+
+def gps_quad_expectation(mu, sigma_s, Q, q, q0):
+    """gps/src/util.cpp:123-134 -> float."""
+    mu, sigma_s, Q, q = map(_f, (mu, sigma_s, Q, q))
+    fn = lib().oracle_gps_quad_expectation
+    fn.restype = C.c_double
+    return float(fn(_p(mu), _p(sigma_s), _p(Q), _p(q), C.c_double(float(q0)), int(mu.shape[0])))
+
+
+def gps_augment_cost(Cxx, cx, Cuu, cu, Cxu, c0, K, kff, sigma_ctl, alpha, dm_state, dm_act, nb_steps,
+                     long_double=False):
+    """gps/src/util.cpp:136-193 -> (agCxx, agcx, agCuu, agcu, agCxu, agc0)."""
+    n, m, T = dm_state, dm_act, nb_steps
+    a = list(map(_f, (Cxx, cx, Cuu, cu, Cxu, c0, K, kff, sigma_ctl, alpha)))
+    z = lambda *s: np.zeros(s, order="F")
+    out = [z(n, n, T + 1), z(n, T + 1), z(m, m, T + 1), z(m, T + 1), z(n, m, T + 1), z(T + 1)]
+    rc = lib().oracle_gps_augment_cost(*map(_p, a), n, m, T, int(long_double), *map(_p, out))
+    if rc:
+        raise np.linalg.LinAlgError("inv_sympd(): sigma_ctl not positive definite at step %d" % (rc - 1))
+    return tuple(out)
+
+
+def gps_forward_pass(mu_x0, sigma_x0, A, B, c, sigma_dyn, K, kff, sigma_ctl, dm_state, dm_act, nb_steps,
+                     long_double=False):
+    """gps/src/util.cpp:195-269 -> (mu_x, sigma_x, mu_u, sigma_u, mu_xu, sigma_xu)."""
+    n, m, T = dm_state, dm_act, nb_steps
+    a = list(map(_f, (mu_x0, sigma_x0, A, B, c, sigma_dyn, K, kff, sigma_ctl)))
+    z = lambda *s: np.zeros(s, order="F")
+    out = [z(n, T + 1), z(n, n, T + 1), z(m, T), z(m, m, T), z(n + m, T + 1), z(n + m, n + m, T + 1)]
+    lib().oracle_gps_forward_pass(*map(_p, a), n, m, T, int(long_double), *map(_p, out))
+    return tuple(out)
+
+
 # ---- A8 / A3 / A4 / A5 / A10 ----------------------------------------------------------------------
 def env_dynamics(e, x, u):
     x, u = _f(x), _f(np.atleast_1d(u))

@@ -284,3 +284,85 @@ def test_gps_positive_definite_quu_is_the_divergence(oracle, mirror):
     o, f = oracle.gps_backward_pass(*args, n, m, T)
     assert f and o[12] == 11 and mirror.gps_backward_pass(*args, n, m, T)["diverge"] == 11
     assert np.all(o[9][..., :11] == 0.0) and np.all(o[9][..., 12:] != 0.0)
+
+
+def _gps_policy(oracle, n, m, T, seed):
+    """A linear-Gaussian controller + state marginals from the oracle's own backward / forward pass."""
+    q = S.problem(S.gps_inputs(n, m, T, 1, seed=seed), 0)
+    o, f = oracle.gps_backward_pass(*[q[k] for k in GPS_ARGS], n, m, T)
+    assert not f
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mu0, R = rng.standard_normal(n), rng.standard_normal((n, n))
+    s0 = 1e-2 * (R.T @ R / n + np.eye(n))
+    return q, o, mu0, s0
+
+
+@pytest.mark.parametrize("n,m,T", [(2, 1, 60), (4, 2, 40), (6, 1, 30), (12, 4, 12)])
+def test_gps_forward_augment_kl_vs_mirror_vs_long_double(oracle, mirror, n, m, T):
+    q, o, mu0, s0 = _gps_policy(oracle, n, m, T, 300 + n)
+    K, kff, sg = o[9], o[10], o[11]
+    fa = (mu0, s0, q["A"], q["B"], q["c"], q["sigma_dyn"], K, kff, sg)
+    fw, fl, fm = (oracle.gps_forward_pass(*fa, n, m, T), oracle.gps_forward_pass(*fa, n, m, T, long_double=True),
+                  mirror.gps_forward_pass(*fa, n, m, T))
+    for k, a, b, c in zip(("mu_x", "sigma_x", "mu_u", "sigma_u", "mu_xu", "sigma_xu"), fw, fl, fm):
+        assert_close(a, b, "ld " + k, tol=1e-10)
+        assert_close(a, c, "mirror " + k, tol=1e-10)
+    aa = (q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["c0"], K, kff, sg, q["alpha"])
+    ag, al, am = (oracle.gps_augment_cost(*aa, n, m, T), oracle.gps_augment_cost(*aa, n, m, T, long_double=True),
+                  mirror.gps_augment_cost(*aa, n, m, T))
+    for k, a, b, c in zip(("Cxx", "cx", "Cuu", "cu", "Cxu", "c0"), ag, al, am):
+        assert_close(a, b, "ld ag" + k, tol=1e-10)
+        assert_close(a, c, "mirror ag" + k, tol=1e-10)
+    rng = np.random.Generator(np.random.PCG64(9))
+    K2, k2, sg2 = K + 0.1 * rng.standard_normal(K.shape), kff + 0.1, 1.5 * sg
+    ka = (K2, k2, sg2, K, kff, sg, fw[0], fw[1])
+    kl, kll, klm = (oracle.gps_kl_divergence(*ka, n, m, T), oracle.gps_kl_divergence(*ka, n, m, T, long_double=True),
+                    mirror.gps_kl_divergence(*ka, n, m, T))
+    assert np.all(kl > 0.0)
+    assert_close(kl, kll, "ld kl", tol=1e-9)
+    assert_close(kl, klm, "mirror kl", tol=1e-9)
+
+
+def test_gps_closed_forms(oracle, mirror):
+    n, m, T = 4, 1, 25
+    q, o, mu0, s0 = _gps_policy(oracle, n, m, T, 11)
+    K, kff, sg = o[9], o[10], o[11]
+    # KL of a controller with itself is zero; scaling sigma by s gives (m/2)(1/s - 1 + log s)... for p = s q
+    fw = oracle.gps_forward_pass(mu0, s0, q["A"], q["B"], q["c"], q["sigma_dyn"], K, kff, sg, n, m, T)
+    assert np.abs(oracle.gps_kl_divergence(K, kff, sg, K, kff, sg, fw[0], fw[1], n, m, T)).max() < 1e-13
+    kl = oracle.gps_kl_divergence(K, kff, 2.0 * sg, K, kff, sg, fw[0], fw[1], n, m, T)
+    np.testing.assert_allclose(kl, 0.5 * m * (2.0 - 1.0 - np.log(2.0)), rtol=1e-12)   # util.cpp:108-110
+    # zero noise: the mean follows the deterministic closed loop x' = A x + B (K x + k) + c
+    z = np.zeros_like
+    fw0 = oracle.gps_forward_pass(mu0, z(s0), q["A"], q["B"], q["c"], z(q["sigma_dyn"]), K, kff, z(sg), n, m, T)
+    x = mu0.copy()
+    for t in range(T):
+        u = K[..., t] @ x + kff[:, t]
+        np.testing.assert_allclose(fw0[2][:, t], u, rtol=1e-12, atol=1e-14)
+        x = q["A"][..., t] @ x + q["B"][..., t] @ u + q["c"][:, t]
+    np.testing.assert_allclose(fw0[0][:, T], x, rtol=1e-11)
+    assert np.abs(fw0[1]).max() == 0.0 and np.abs(fw0[5]).max() == 0.0
+    # the joint covariance holds the marginals; last slice: state block only (util.cpp:253-256)
+    assert np.array_equal(fw[5][:n, :n, T], fw[1][..., T]) and np.all(fw[5][n:, :, T] == 0.0)
+    assert np.all(fw[4][n:, T] == 0.0)
+    np.testing.assert_allclose(fw[5][n:, n:, 3], fw[3][..., 3], rtol=1e-14)
+    # alpha = 0 leaves the cost alone; the last slice is always a copy (util.cpp:176-181)
+    aa = (q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["c0"], K, kff, sg)
+    ag = oracle.gps_augment_cost(*aa, np.zeros(T), n, m, T)
+    for a, b in zip(ag, aa[:6]):
+        assert np.array_equal(a, b)
+    ag = oracle.gps_augment_cost(*aa, q["alpha"], n, m, T)
+    assert np.array_equal(ag[0][..., T], q["Cxx"][..., T]) and ag[5][T] == q["c0"][T]
+    # m = 1: agCuu = Cuu + alpha / (2 sigma)
+    np.testing.assert_allclose(ag[2][0, 0, :T], q["Cuu"][0, 0, :T] + 0.5 * q["alpha"] / sg[0, 0, :], rtol=1e-13)
+    # E[x'Qx + q'x + q0] with zero covariance is the quadratic itself
+    V, v, v0 = o[6][..., 0], o[7][:, 0], o[8][0]
+    assert oracle.gps_quad_expectation(mu0, z(s0), V, v, v0) == pytest.approx(mu0 @ V @ mu0 + mu0 @ v + v0, rel=1e-13)
+    assert oracle.gps_quad_expectation(mu0, s0, V, v, v0) == pytest.approx(
+        mirror.gps_quad_expectation(mu0, s0, V, v, v0), rel=1e-12)
+    # a covariance that is not positive definite is an error, as Armadillo's inv_sympd()
+    bad = sg.copy(); bad[..., 5] = -1.0
+    with pytest.raises(np.linalg.LinAlgError):
+        oracle.gps_augment_cost(*aa[:8], bad, q["alpha"], n, m, T)
+    with pytest.raises(np.linalg.LinAlgError):
+        oracle.gps_kl_divergence(K, kff, sg, K, kff, bad, fw[0], fw[1], n, m, T)

@@ -85,6 +85,9 @@ EXPORTS = (
     "trajopt_ilqr_backward_pass_host", "trajopt_ilqr_backward_pass_batched",
     "trajopt_backward_supports_structured_cost",
     "trajopt_gps_backward_supported", "trajopt_gps_backward_pass_batched", "trajopt_gps_backward_pass_host",
+    "trajopt_gps_forward_pass_batched", "trajopt_gps_augment_cost_batched", "trajopt_gps_kl_divergence_batched",
+    "trajopt_gps_quad_expectation_batched", "trajopt_gps_forward_pass_host", "trajopt_gps_augment_cost_host",
+    "trajopt_gps_kl_divergence_host", "trajopt_gps_quad_expectation_host",
     "trajopt_riccati_backward_pass_host", "trajopt_riccati_backward_pass_batched",
     "trajopt_env_step_batched", "trajopt_ilqr_forward_pass_batched", "trajopt_quadratize_batched",
     "trajopt_ilqr_init_rollout", "trajopt_ilqr_iterate", "trajopt_convert_layout",

@@ -127,3 +127,82 @@ def gps_backward_pass(Cxx, cx, Cuu, cu, Cxu, c0, A, B, c, sigma_dyn, alpha, dm_s
     io.diverge, io.status = dptr(o["diverge"]), dptr(o["status"])
     check(lib().trajopt_gps_backward_pass_batched(C.byref(io), n, m, T, C.c_int64(N), int(layout), stream_ptr()))
     return o
+
+
+def _gps_check(tensors, N):
+    for t, cnt, nm in tensors:
+        _chk(t, cnt * N, nm)
+
+
+def gps_forward_pass(mu_x0, sigma_x0, A, B, c, sigma_dyn, K, kff, sigma_ctl, dm_state, dm_act, nb_steps, nb_problems,
+                     layout=LAYOUT_PROBLEM_MINOR):
+    """Gaussian moment propagation of gps/src/util.cpp:195-269 for a batch -> dict mu_x, sigma_x, mu_u, sigma_u,
+    mu_xu, sigma_xu.  mu_x0 / sigma_x0 are (N, n) / (N, n, n) in `layout` (device shapes (n, N) / (n, n, N))."""
+    _lib.require_gpu()
+    n, m, T, N = dm_state, dm_act, nb_steps, nb_problems
+    _gps_check(((mu_x0, n, "mu_x0"), (sigma_x0, n * n, "sigma_x0"), (A, n * n * T, "A"), (B, n * m * T, "B"),
+                (c, n * T, "c"), (sigma_dyn, n * n * T, "sigma_dyn"), (K, n * m * T, "K"), (kff, m * T, "kff"),
+                (sigma_ctl, m * m * T, "sigma_ctl")), N)
+    dev, w = A.device, n + m
+    o = dict(mu_x=empty((N, n, T + 1), layout, dev), sigma_x=empty((N, n, n, T + 1), layout, dev),
+             mu_u=empty((N, m, T), layout, dev), sigma_u=empty((N, m, m, T), layout, dev),
+             mu_xu=empty((N, w, T + 1), layout, dev), sigma_xu=empty((N, w, w, T + 1), layout, dev))
+    check(lib().trajopt_gps_forward_pass_batched(
+        *map(dptr, (mu_x0, sigma_x0, A, B, c, sigma_dyn, K, kff, sigma_ctl)), n, m, T, C.c_int64(N), int(layout),
+        *[dptr(o[k]) for k in ("mu_x", "sigma_x", "mu_u", "sigma_u", "mu_xu", "sigma_xu")], stream_ptr()))
+    return o
+
+
+def gps_augment_cost(Cxx, cx, Cuu, cu, Cxu, c0, K, kff, sigma_ctl, alpha, dm_state, dm_act, nb_steps, nb_problems,
+                     layout=LAYOUT_PROBLEM_MINOR):
+    """gps/src/util.cpp:136-193 for a batch -> dict Cxx, cx, Cuu, cu, Cxu, c0 (T+1 slices) and status."""
+    import torch
+    _lib.require_gpu()
+    n, m, T, N = dm_state, dm_act, nb_steps, nb_problems
+    _gps_check(((Cxx, n * n * (T + 1), "Cxx"), (cx, n * (T + 1), "cx"), (Cuu, m * m * (T + 1), "Cuu"),
+                (cu, m * (T + 1), "cu"), (Cxu, n * m * (T + 1), "Cxu"), (c0, T + 1, "c0"), (K, n * m * T, "K"),
+                (kff, m * T, "kff"), (sigma_ctl, m * m * T, "sigma_ctl"), (alpha, T, "alpha")), N)
+    dev = Cxx.device
+    o = dict(Cxx=empty((N, n, n, T + 1), layout, dev), cx=empty((N, n, T + 1), layout, dev),
+             Cuu=empty((N, m, m, T + 1), layout, dev), cu=empty((N, m, T + 1), layout, dev),
+             Cxu=empty((N, n, m, T + 1), layout, dev), c0=empty((N, T + 1), layout, dev),
+             status=torch.empty(N, dtype=torch.int32, device=dev))
+    check(lib().trajopt_gps_augment_cost_batched(
+        *map(dptr, (Cxx, cx, Cuu, cu, Cxu, c0, K, kff, sigma_ctl, alpha)), n, m, T, C.c_int64(N), int(layout),
+        *[dptr(o[k]) for k in ("Cxx", "cx", "Cuu", "cu", "Cxu", "c0", "status")], stream_ptr()))
+    return o
+
+
+def gps_kl_divergence(p_K, p_kff, p_sigma_ctl, q_K, q_kff, q_sigma_ctl, mu_x, sigma_x, dm_state, dm_act, nb_steps,
+                      nb_problems, layout=LAYOUT_PROBLEM_MINOR):
+    """gps/src/util.cpp:83-121 for a batch -> (kl (N, T) in `layout`, status).  mu_x / sigma_x may hold T or T+1
+    slices (time is the slowest device axis in PROBLEM_MINOR, so the first T are a prefix)."""
+    import torch
+    _lib.require_gpu()
+    n, m, T, N = dm_state, dm_act, nb_steps, nb_problems
+    _gps_check(((p_K, n * m * T, "p_K"), (p_kff, m * T, "p_kff"), (p_sigma_ctl, m * m * T, "p_sigma_ctl"),
+                (q_K, n * m * T, "q_K"), (q_kff, m * T, "q_kff"), (q_sigma_ctl, m * m * T, "q_sigma_ctl")), N)
+    for t, per, nm in ((mu_x, n, "mu_x"), (sigma_x, n * n, "sigma_x")):
+        if t.numel() not in (per * T * N, per * (T + 1) * N) or (t.numel() != per * T * N and N != 1 and
+                                                                 layout != LAYOUT_PROBLEM_MINOR):
+            raise ValueError("%s must hold %d or %d slices (the latter only in PROBLEM_MINOR)" % (nm, T, T + 1))
+        _chk(t, t.numel(), nm)
+    dev = p_K.device
+    kl = empty((N, T), layout, dev)
+    status = torch.empty(N, dtype=torch.int32, device=dev)
+    check(lib().trajopt_gps_kl_divergence_batched(
+        *map(dptr, (p_K, p_kff, p_sigma_ctl, q_K, q_kff, q_sigma_ctl, mu_x, sigma_x)), n, m, T, C.c_int64(N),
+        int(layout), dptr(kl), dptr(status), stream_ptr()))
+    return kl, status
+
+
+def gps_quad_expectation(mu, sigma_s, Q, q, q0, dm_state, nb_problems, layout=LAYOUT_PROBLEM_MINOR):
+    """gps/src/util.cpp:123-134 for a batch -> [N] tensor.  mu, q: (N, n); sigma_s, Q: (N, n, n); q0: [N]."""
+    import torch
+    _lib.require_gpu()
+    n, N = dm_state, nb_problems
+    _gps_check(((mu, n, "mu"), (sigma_s, n * n, "sigma_s"), (Q, n * n, "Q"), (q, n, "q"), (q0, 1, "q0")), N)
+    out = torch.empty(N, dtype=torch.float64, device=mu.device)
+    check(lib().trajopt_gps_quad_expectation_batched(*map(dptr, (mu, sigma_s, Q, q, q0)), n, C.c_int64(N),
+                                                     int(layout), dptr(out), stream_ptr()))
+    return out

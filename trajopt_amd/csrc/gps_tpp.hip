@@ -10,7 +10,7 @@
 // step temporaries in VGPRs, the next step's inputs loaded (unconditionally, index clamped) before this step's
 // arithmetic.  MBGPS calls this pass dozens of times per dual solve (gps/mbgps.py:135-201) with small systems, so the
 // shapes instantiated are the reference's own: du <= 2.
-#include "smallmat.h"
+#include "gps_common.h"
 
 namespace trajopt {
 
@@ -27,17 +27,6 @@ struct GpsIn {
 // sigma_dyn[t] and Cxx[t] are not part of the prefetched set: the step loads them at its top and first uses them
 // after the V'F products, which keeps two sets + V + the step temporaries inside 512 VGPRs at dx = 6.
 
-template <int R>
-__device__ __forceinline__ void gld(double (&x)[R], const double* arr, size_t E, int t, size_t NP, size_t p) {
-#pragma unroll
-    for (int e = 0; e < R; ++e) x[e] = arr[((size_t)t * E + e) * NP + p];
-}
-template <int R>
-__device__ __forceinline__ void gst(double* arr, size_t E, int t, size_t NP, size_t p, const double (&x)[R]) {
-#pragma unroll
-    for (int e = 0; e < R; ++e) arr[((size_t)t * E + e) * NP + p] = x[e];
-}
-
 template <int N, int M>
 __device__ __forceinline__ void gps_load(GpsIn<N, M>& s, const trajopt_gps_backward_io_t& io, int t, size_t NP, size_t p) {
     gld<N * N>(s.A, io.A, N * N, t, NP, p);
@@ -49,21 +38,6 @@ __device__ __forceinline__ void gps_load(GpsIn<N, M>& s, const trajopt_gps_backw
     gld<M>(s.cu, io.cu, M, t, NP, p);
     s.c0 = io.c0[(size_t)t * NP + p];
     s.alpha = io.alpha[(size_t)t * NP + p];
-}
-
-// inverse and determinant of an M x M matrix (M <= 2), the general inv() of util.cpp:338; false when singular
-template <int M>
-__device__ __forceinline__ bool small_inv(const double (&X)[M * M], double (&Xi)[M * M], double& det) {
-    static_assert(M == 1 || M == 2, "instantiated for du <= 2");
-    if constexpr (M == 1) {
-        det = X[0];
-        Xi[0] = 1.0 / X[0];
-    } else {
-        det = X[0] * X[3] - X[2] * X[1];
-        const double id = 1.0 / det;
-        Xi[0] = X[3] * id; Xi[1] = -X[1] * id; Xi[2] = -X[2] * id; Xi[3] = X[0] * id;
-    }
-    return det != 0.0 && det == det;
 }
 
 template <int N, int M, bool FULL>
@@ -269,9 +243,7 @@ using namespace trajopt;
 
 extern "C" {
 
-int trajopt_gps_backward_supported(int n, int m) {
-    return ((m == 1 && (n == 2 || n == 3 || n == 4 || n == 6)) || (m == 2 && (n == 2 || n == 4))) ? 1 : 0;
-}
+int trajopt_gps_backward_supported(int n, int m) { return gps_shape_supported(n, m) ? 1 : 0; }
 
 int trajopt_gps_backward_pass_batched(const trajopt_gps_backward_io_t* io, int n, int m, int T, int64_t NP, int layout,
                                       void* stream) {

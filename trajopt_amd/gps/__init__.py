@@ -1,2 +1,3 @@
-"""GPS widening row: the max-entropy backward pass of trajopt.gps.core on the GPU."""
-from .core import backward_pass, backward_pass_status  # noqa: F401
+"""GPS widening row: the native module `trajopt.gps.core` on the GPU."""
+from .core import (augment_cost, backward_pass, backward_pass_status, forward_pass, kl_divergence,  # noqa: F401
+                   quad_expectation)
