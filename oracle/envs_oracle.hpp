@@ -160,6 +160,15 @@ template <class X> void f_quadrotor(const trajopt_env_t& e, const X* x, const X*
     dx[11] = (tz - (Iyy - Ixx) * p * q) / Izz;
 }
 
+template <class X> void f_robot(const trajopt_env_t& e, const X* x, const X* u, X* dx) {
+    // robot.py:53-61
+    const double l = e.phys[0];
+    dx[0] = x[3] * cos(x[2]);
+    dx[1] = x[3] * sin(x[2]);
+    dx[2] = x[3] * tan(u[1]) / l;
+    dx[3] = u[0];
+}
+
 template <class X> void vector_field(const trajopt_env_t& e, const X* x, const X* u, X* dx) {
     switch (e.model) {
         case TRAJOPT_ENV_PENDULUM: f_pendulum(e, x, u, dx); break;
@@ -167,6 +176,7 @@ template <class X> void vector_field(const trajopt_env_t& e, const X* x, const X
         case TRAJOPT_ENV_DOUBLE_CARTPOLE: f_double_cartpole(e, x, u, dx); break;
         case TRAJOPT_ENV_QUADROTOR: f_quadrotor(e, x, u, dx); break;
         case TRAJOPT_ENV_DOUBLE_PENDULUM: f_double_pendulum(e, x, u, dx); break;
+        case TRAJOPT_ENV_ROBOT: f_robot(e, x, u, dx); break;
         default: break;
     }
 }
@@ -187,7 +197,7 @@ template <class X> void dynamics(const trajopt_env_t& e, const X* x, const X* u,
         }
         return;
     }
-    const double dt = e.dt;
+    const double dt = e.model == TRAJOPT_ENV_ROBOT ? -e.dt : e.dt;  // robot.py:62-67 steps RK4 by -dt
     X k1[TRAJOPT_ENV_MAX_STATE], k2[TRAJOPT_ENV_MAX_STATE], k3[TRAJOPT_ENV_MAX_STATE], k4[TRAJOPT_ENV_MAX_STATE],
         y[TRAJOPT_ENV_MAX_STATE];
     vector_field(e, x, uc, k1);

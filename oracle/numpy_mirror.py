@@ -138,8 +138,20 @@ class Env:
     """Parameter bag with the reference's constants; `name` selects the vector field."""
 
     def __init__(self, name, dt=None, uw=None, slew_rate=False, periodic=False, **kw):
-        self.name, self.slew_rate, self.periodic = name, slew_rate, periodic
         inf = np.inf
+        lqr_dt = 0.1
+        if name in ("lqr_v1", "lqr_v2"):   # lqr_v1.py:10-37, lqr_v2.py:10-36: other constants, same affine model
+            lqr_dt = 0.01 if dt is None else dt
+            if name == "lqr_v1":
+                mm, k, d = 1., 1e-2, 1e-1
+                kw = dict(A=np.array([[0., 1.], [-k / mm, -d / mm]]) * 0.01 + np.eye(2),   # the constructor's dt
+                          B=np.array([[0.], [1. / mm]]) * 0.01, gw=[1e2, 1e0])
+            else:
+                kw = dict(A=[[1.0, 0.], [0.1, 1.1]], B=[[0.05], [0.]], gw=[1e1, 1e0])
+            kw.update(goal=[1., 0.], c=[0., 0.])
+            uw = [1e-3] if uw is None else uw
+            name = "lqr"
+        self.name, self.slew_rate, self.periodic = name, slew_rate, periodic
         self.cost_times_dt = False
         if name == "pendulum":
             self.n, self.m, self.dt = 2, 1, 0.01
@@ -165,11 +177,17 @@ class Env:
             self.A = np.asarray(kw.get("A", [[1.1, 0.], [1.0, 1.0]]), dtype=float)
             self.B = np.asarray(kw.get("B", [[1.], [0.]]), dtype=float)
             self.n, self.m = self.B.shape
-            self.dt = 0.1
+            self.dt = lqr_dt
             self.g = np.asarray(kw.get("goal", [10., 10.]), dtype=float)
             self.c = np.asarray(kw.get("c", -self.A @ self.g), dtype=float)
             self.gw, self.uw = np.asarray(kw.get("gw", [1e1] * self.n), dtype=float), np.ones(self.m)
             self.umax, self.xmax = np.full(self.m, inf), np.full(self.n, inf)
+            self.cost_times_dt = True
+            self.angles = []
+        elif name == "robot":
+            self.n, self.m, self.dt = 4, 2, 0.025
+            self.umax, self.xmax = np.full(2, inf), np.full(4, inf)
+            self.g, self.gw, self.uw = np.zeros(4), np.array([1e1, 1e1, 1., 1.]), np.full(2, 1e-3)
             self.cost_times_dt = True
             self.angles = []
         elif name == "quadrotor":
@@ -252,6 +270,8 @@ class Env:
                              cph * cth * F / mass - g,
                              (tx - (Izz - Iyy) * q * r) / Ixx, (ty - (Ixx - Izz) * p * r) / Iyy,
                              (tz - (Iyy - Ixx) * p * q) / Izz])
+        if nm == "robot":
+            return np.array([x[3] * np.cos(x[2]), x[3] * np.sin(x[2]), x[3] * np.tan(u[1]) / 0.1, u[0]])
         raise KeyError(nm)
 
     def dynamics(self, x, u):
@@ -259,7 +279,7 @@ class Env:
         _u = _clip(u, self.umax)
         if self.name == "lqr":
             return self.A @ x + self.B @ _u + self.c
-        dt = self.dt
+        dt = -self.dt if self.name == "robot" else self.dt   # robot.py:62-67
         k1 = self.f(x, _u)
         k2 = self.f(x + 0.5 * dt * k1, _u)
         k3 = self.f(x + 0.5 * dt * k2, _u)

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 MAX_STATE, MAX_ACT = 12, 4
-ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR, ENV_DOUBLE_PENDULUM = 1, 2, 3, 4, 5, 6
+ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR, ENV_DOUBLE_PENDULUM, ENV_ROBOT = 1, 2, 3, 4, 5, 6, 7
 
 
 class EnvStruct(C.Structure):
@@ -114,6 +114,27 @@ def make_env(name, dt=None, uw=None, slew_rate=False, periodic=False, **kw):
         fill(e.gw, [1e4, 1e4, 1e0, 1e0]); fill(e.uw, [1e-5] * 2 if uw is None else uw)
         fill(e.phys, [9.81, 1., 1., 1., 1., 0.025, 0.025])
         e.periodic = 0b0001 if periodic else 0
+    elif name == "robot":  # envs/robot/robot.py:10-36
+        e.model, e.dm_state, e.dm_act = ENV_ROBOT, 4, 2
+        e.dt = 0.025 if dt is None else dt
+        e.cost_times_dt = 1
+        fill(e.umax, [inf] * 2); fill(e.xmax, [inf] * 4); fill(e.goal, [0.] * 4)
+        fill(e.gw, [1e1, 1e1, 1., 1.]); fill(e.uw, [1e-3] * 2 if uw is None else uw)
+        fill(e.phys, [0.1])
+    elif name in ("lqr_v1", "lqr_v2"):  # envs/lqr/lqr_v1.py:10-37, lqr_v2.py:10-36
+        e.model, e.dm_state, e.dm_act = ENV_LQR, 2, 1
+        e.dt = 0.01 if dt is None else dt
+        e.cost_times_dt = 1
+        if name == "lqr_v1":
+            mm, k, d = 1., 1e-2, 1e-1
+            A = np.array([[0., 1.], [-k / mm, -d / mm]]) * 0.01 + np.eye(2)   # built with the constructor's dt
+            B = np.array([[0.], [1. / mm]]) * 0.01
+            gw = [1e2, 1e0]
+        else:
+            A, B, gw = np.array([[1.0, 0.], [0.1, 1.1]]), np.array([[0.05], [0.]]), [1e1, 1e0]
+        fill(e.umax, [inf]); fill(e.xmax, [inf] * 2); fill(e.goal, [1., 0.])
+        fill(e.gw, gw); fill(e.uw, [1e-3] if uw is None else uw)
+        fill(e.lin_A, A.flatten(order="F")); fill(e.lin_B, B.flatten(order="F")); fill(e.lin_c, [0., 0.])
     elif name == "quadrotor":  # build-defined, not in the reference
         e.model, e.dm_state, e.dm_act = ENV_QUADROTOR, 12, 4
         e.dt = 0.01 if dt is None else dt

@@ -9,7 +9,7 @@ from tests.util import TOL, assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
-ENVS = ["pendulum", "cartpole", "double_cartpole", "quadrotor", "lqr", "double_pendulum"]
+ENVS = ["pendulum", "cartpole", "double_cartpole", "quadrotor", "lqr", "double_pendulum", "robot", "lqr_v1", "lqr_v2"]
 
 
 def _pair(name, **kw):
@@ -25,7 +25,8 @@ def _pair(name, **kw):
 
 
 def _rand_state(name, rng, N):
-    n = {"pendulum": 2, "cartpole": 4, "double_cartpole": 6, "quadrotor": 12, "lqr": 2, "double_pendulum": 4}[name]
+    n = {"pendulum": 2, "cartpole": 4, "double_cartpole": 6, "quadrotor": 12, "lqr": 2, "double_pendulum": 4, "robot": 4,
+         "lqr_v1": 2, "lqr_v2": 2}[name]
     x = rng.standard_normal((N, n))
     if name == "quadrotor":
         x[:, 3:6] *= 0.3  # keep away from the Euler singularity
@@ -34,7 +35,7 @@ def _rand_state(name, rng, N):
 
 def test_env_struct_matches_oracle_struct():
     for name in ENVS:
-        for kw in ({}, dict(dt=0.05, uw=[1e-2] * {"quadrotor": 4, "double_pendulum": 2}.get(name, 1), slew_rate=True, periodic=True)):
+        for kw in ({}, dict(dt=0.05, uw=[1e-2] * {"quadrotor": 4, "double_pendulum": 2, "robot": 2}.get(name, 1), slew_rate=True, periodic=True)):
             pe, oe = _pair(name, **kw)
             assert bytes(pe.struct()) == bytes(oe), name
 
@@ -44,7 +45,7 @@ def test_env_struct_matches_oracle_struct():
 def test_env_step_matches_oracle(oracle, name, layout):
     import torch
     from trajopt_amd import _lib, layout as L
-    pe, oe = _pair(name, slew_rate=True, periodic=(name != "lqr" and name != "quadrotor"))
+    pe, oe = _pair(name, slew_rate=True, periodic=(name in ("pendulum", "cartpole", "double_cartpole", "double_pendulum")))
     rng = np.random.default_rng(3)
     N = 130
     n, m = pe.dm_state, pe.dm_act
@@ -81,6 +82,8 @@ def _rollout_inputs(name, rng, N, T, n, m):
     kff = (0.1 if name == "quadrotor" else 1.0) * rng.standard_normal((N, m, T))
     if name == "quadrotor":
         uref = 1.2 + 0.05 * uref
+    if name == "robot":   # steering angle: tan(phi) / l = 10 tan(phi) turns round-off into O(1) near its poles
+        K[:, 1], kff[:, 1], uref[:, 1] = 0.03 * K[:, 1], 0.1 * kff[:, 1], 0.2 * uref[:, 1]
     x0 = xref[:, :, 0] + 0.05 * rng.standard_normal((N, n))
     return x0, K, kff, xref, uref
 
@@ -141,7 +144,9 @@ def test_quadratize_matches_oracle(oracle, name, layout, convention):
     n, m = pe.dm_state, pe.dm_act
     xref = 2.0 * _rand_state(name, rng, N)[:, :, None] + 0.3 * rng.standard_normal((N, n, T + 1))
     uref = 6.0 * rng.standard_normal((N, m, T))    # some saturated -> B columns vanish
-    uref[:, :, 3] = np.asarray(pe.umax) if name != "lqr" else 1.0   # exactly on the bound
+    uref[:, :, 3] = np.asarray(pe.umax) if np.all(np.isfinite(pe.umax)) else 1.0   # exactly on the bound
+    if name == "robot":
+        uref[:, 1] = 0.4 * np.tanh(uref[:, 1])    # steering angle away from tan's poles
     w = rng.uniform(0.5, 1.5, T + 1)
     w[2] = 0.0
     e = pe.struct()
@@ -184,6 +189,9 @@ def _solve_pair(oracle, name, N, T, iters, seed=1337, scale=1e-2, gains_layout=N
     ("quadrotor", 40, 3, dict(dt=0.02)),                      # gains group defaults to PROBLEM_MAJOR (dx > 6)
     ("lqr", 60, 5, dict()),
     ("double_pendulum", 50, 4, dict(dt=0.02)),                # a further env model, dx = 4, du = 2
+    ("robot", 50, 4, dict()),                                 # 8f.3: dx = 4, du = 2, RK4 by -dt, cost x dt
+    ("lqr_v1", 60, 4, dict()),
+    ("lqr_v2", 60, 4, dict()),
     ("cartpole", 40, 4, dict(dt=0.02, uw=[1e-5], gains_layout=0)),          # forced PROBLEM_MAJOR gains group
     ("double_cartpole", 30, 3, dict(dt=0.01, uw=[1e-5], gains_layout=0)),
     ("quadrotor", 30, 2, dict(dt=0.02, gains_layout=1)),                    # forced PROBLEM_MINOR

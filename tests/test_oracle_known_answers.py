@@ -178,7 +178,7 @@ def test_is_sympd_rule(oracle, mirror):
 
 
 ENVS = [("pendulum", dict(dt=0.05)), ("cartpole", dict(dt=0.02)), ("double_cartpole", dict()), ("quadrotor", dict()),
-        ("lqr", dict()), ("double_pendulum", dict(dt=0.02))]
+        ("lqr", dict()), ("double_pendulum", dict(dt=0.02)), ("robot", dict()), ("lqr_v1", dict()), ("lqr_v2", dict())]
 
 
 @pytest.mark.parametrize("name,kw", ENVS)
@@ -191,6 +191,8 @@ def test_env_models_and_derivatives_vs_mirror(oracle, mirror, name, kw):
         if name == "quadrotor":
             x[3:6] *= 0.3
         u = 3.0 * rng.standard_normal(me.m) if trial % 3 else 20.0 * np.ones(me.m)  # saturated every 3rd
+        if name == "robot":
+            u[1] = 0.4 * np.tanh(u[1])   # steering angle away from tan's poles
         ul = rng.standard_normal(me.m)
         np.testing.assert_allclose(oracle.env_dynamics(e, x, u), me.dynamics(x, u), rtol=1e-12, atol=1e-13)
         assert oracle.env_cost(e, x, u, ul, 0.7) == pytest.approx(me.cost(x, u, ul, 0.7), rel=1e-12)
@@ -199,7 +201,7 @@ def test_env_models_and_derivatives_vs_mirror(oracle, mirror, name, kw):
         mA, mB = me.jacobians(x, u)
         np.testing.assert_allclose(A, mA, rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(B, mB, rtol=1e-10, atol=1e-12)
-        if trial % 3 == 0 and name != "lqr":
+        if trial % 3 == 0 and np.all(np.isfinite(me.umax)):   # the LQR envs and the robot have no action limit
             assert not np.any(B)  # quirk 10: clip derivative is 0 on the bound
 
 

@@ -245,6 +245,25 @@ template <> struct Model<TRAJOPT_ENV_DOUBLE_PENDULUM> {
     }
 };
 
+template <> struct Model<TRAJOPT_ENV_ROBOT> {
+    static constexpr int N = 4, M = 2;
+    template <class X> static __device__ __forceinline__ void f(const trajopt_env_t& e, const X (&x)[N], const X (&u)[M], X (&dx)[N]) {
+        // robot.py:53-61: x = [x, y, th, v], u = [a, phi];  phys = {l}
+        const double il = 1.0 / e.phys[0];
+        X s, c, sp, cp;
+        sincos_g(x[2], s, c);
+        sincos_g(u[1], sp, cp);
+        dx[0] = x[3] * c;
+        dx[1] = x[3] * s;
+        dx[2] = x[3] * (sp * recip_g(cp)) * il;   // v tan(phi) / l
+        dx[3] = u[0];
+    }
+};
+
+// robot.py:62-67 integrates with x - dt/2 k, x - dt k and xn = x - dt/6 (...): RK4 with the step -dt.  Kept as is.
+template <int MODEL> struct ReverseTime { static constexpr bool value = false; };
+template <> struct ReverseTime<TRAJOPT_ENV_ROBOT> { static constexpr bool value = true; };
+
 template <> struct Model<TRAJOPT_ENV_QUADROTOR> {
     static constexpr int N = 12, M = 4;
     template <class X> static __device__ __forceinline__ void f(const trajopt_env_t& e, const X (&x)[N], const X (&u)[M], X (&dx)[N]) {
@@ -282,7 +301,7 @@ __device__ __forceinline__ void env_dynamics(const trajopt_env_t& e, const X (&x
     X uc[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) uc[j] = UCLIP ? clip_g(u[j], e.umax[j]) : u[j];
-    const double dt = e.dt;
+    const double dt = ReverseTime<MODEL>::value ? -e.dt : e.dt;
     X k1[N], k2[N], k3[N], k4[N], y[N];
     Model<MODEL>::f(e, x, uc, k1);
 #pragma unroll

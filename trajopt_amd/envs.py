@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_DOUBLE_PENDULUM, ENV_LQR, ENV_PENDULUM, ENV_QUADROTOR, MAX_ACT, MAX_STATE,
+from ._lib import (ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_DOUBLE_PENDULUM, ENV_LQR, ENV_PENDULUM, ENV_QUADROTOR, ENV_ROBOT, MAX_ACT, MAX_STATE,
                    EnvStruct)
 
 
@@ -240,6 +240,42 @@ class LQRv0(Env):
             e.lin_c[k] = float(v)
 
 
+class LQRv1(LQRv0):
+    """/root/reference/trajopt/envs/lqr/lqr_v1.py:8-109: Euler-discretised mass-spring-damper (the deterministic
+    `dist=None` dynamics; the sampled-parameter branch :60-65 belongs to rGPS, out of scope)."""
+
+    def __init__(self, dt=0.01):
+        m, k, d = 1., 1e-2, 1e-1
+        super().__init__(A=np.array([[0., 1.], [-k / m, -d / m]]) * dt + np.eye(2), B=np.array([[0.], [1. / m]]) * dt,
+                         c=np.zeros(2), g=np.array([1., 0.]), gw=np.array([1e2, 1e0]), uw=np.array([1e-3]),
+                         x0=np.zeros(2), dt=dt)
+        self.sigma0 = 1e-4 * np.eye(2)
+
+
+class LQRv2(LQRv0):
+    """/root/reference/trajopt/envs/lqr/lqr_v2.py:8-106 (deterministic dynamics, as LQRv1)."""
+
+    def __init__(self, dt=0.01):
+        super().__init__(A=np.array([[1.0, 0.], [0.1, 1.1]]), B=np.array([[0.05], [0.]]), c=np.zeros(2),
+                         g=np.array([1., 0.]), gw=np.array([1e1, 1e0]), uw=np.array([1e-3]), x0=np.full(2, 5.), dt=dt)
+
+
+class Robot(Env):
+    """/root/reference/trajopt/envs/robot/robot.py:8-102: car-like robot x = [x, y, th, v], u = [a, phi]; cost scaled
+    by dt; its RK4 steps by -dt (robot.py:62-67), kept."""
+    model, cost_times_dt = ENV_ROBOT, True
+    phys = (0.1,)  # car length (robot.py:17)
+
+    def __init__(self):
+        self.dm_state, self.dm_act, self.dt = 4, 2, 0.025
+        self.sigma = 1e-8 * np.eye(4)
+        self.g, self.gw = np.zeros(4), np.array([1e1, 1e1, 1., 1.])
+        self.xmax = np.full(4, np.inf)
+        self.uw, self.umax = 1e-3 * np.ones(2), np.full(2, np.inf)
+        self.x0, self.sigma0 = np.array([5., 5., 0., 0.]), 1e-4 * np.eye(4)
+        super().__init__()
+
+
 class Quadrotor(Env):
     """Build-defined 12-state rigid body with 4 rotor thrusts (BASELINE config C4).  NOT in the reference:
     its nearest env is QuadPendulum (dx=8, du=4).  x = [p(3), roll/pitch/yaw, v(3), body rates], u = thrusts."""
@@ -261,6 +297,7 @@ _REGISTRY = {
     # the reference's gym ids (/root/reference/trajopt/__init__.py:3-97) for the envs in scope
     "Pendulum-TO-v0": Pendulum, "Cartpole-TO-v0": Cartpole, "DoubleCartpole-TO-v0": DoubleCartpole,
     "LQR-TO-v0": LQRv0, "DoublePendulum-TO-v0": DoublePendulum, "double_pendulum": DoublePendulum,
+    "LQR-TO-v1": LQRv1, "LQR-TO-v2": LQRv2, "Robot-TO-v0": Robot, "lqr_v1": LQRv1, "lqr_v2": LQRv2, "robot": Robot,
     "pendulum": Pendulum, "cartpole": Cartpole, "double_cartpole": DoubleCartpole, "lqr": LQRv0,
     "quadrotor": Quadrotor, "Quadrotor-TO-v0": Quadrotor,
 }
