@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TRAJOPT_ABI_VERSION 2
+#define TRAJOPT_ABI_VERSION 3
 
 #define TRAJOPT_OK 0
 #define TRAJOPT_ERR_BAD_ARG (-1)      /* null pointer, non-positive size, unknown enum            */

@@ -22,6 +22,11 @@ extern "C" {
 #define TRAJOPT_ENV_MAX_STATE 12
 #define TRAJOPT_ENV_MAX_ACT 4
 
+#define TRAJOPT_FEAT_ID 0
+#define TRAJOPT_FEAT_COS 1
+#define TRAJOPT_FEAT_SIN 2
+#define TRAJOPT_FEATURE(kind, state) (((kind) << 8) | (state))
+
 /* model ids */
 enum {
     TRAJOPT_ENV_PENDULUM = 1,        /* envs/pendulum/pendulum.py:15-149           dx=2 du=1 */
@@ -40,6 +45,13 @@ typedef struct trajopt_env {
     int32_t slew_rate;    /* cost on (u - u_last) instead of u   (cartpole.py:115-118)       */
     int32_t periodic;     /* wrap angle states before the cost   (cartpole.py:121-122)       */
     int32_t cost_times_dt;/* LQR envs scale the whole cost by dt (lqr_v0.py:94)              */
+    /* State-cost features z = phi(y) of the "...WithCartesianCost" envs (e.g. cartpole.py:150-166): 0 = identity
+     * (z = y, goal / gw hold dm_state entries); else goal / gw hold nb_features entries and feature f is
+     * TRAJOPT_FEAT_{ID,COS,SIN} of state (features[f] & 0xff), kind in bits 8-9.  The Jacobian of phi is frozen in
+     * the derivatives (getval, cartpole.py:122-124): cx = 2a J'G(z - g), Cxx = 2a J'GJ (Gauss-Newton).              */
+    int32_t nb_features;
+    int32_t features[TRAJOPT_ENV_MAX_STATE];
+    int32_t reserved0;    /* keeps the doubles 8-byte aligned                                */
     double dt;            /* RK4 step                                                        */
     double umax[TRAJOPT_ENV_MAX_ACT];    /* action clip  (+inf allowed)                      */
     double xmax[TRAJOPT_ENV_MAX_STATE];  /* state clip   (+inf allowed)                      */

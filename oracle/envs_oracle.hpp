@@ -219,7 +219,18 @@ inline double wrap_angle(double x) {  // cartpole.py:10-12, Python's % (sign of 
     return r - M_PI;
 }
 
-// env.cost(x, u, u_last, a) with identity features (cartpole.py:99-105,112-127): J = I, j = 0.
+// Feature f of trajopt_env_t::features at x (after the periodic wrap) and its derivative w.r.t. its one state
+// (e.g. cartpole.py:161-166: [x0, cos x1, sin x1, x2, x3]).
+inline double feature(const trajopt_env_t& e, const double* x, int f, double* dz) {
+    const int i = e.features[f] & 0xff, kind = e.features[f] >> 8;
+    const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
+    if (kind == TRAJOPT_FEAT_COS) { *dz = -std::sin(y); return std::cos(y); }
+    if (kind == TRAJOPT_FEAT_SIN) { *dz = std::cos(y); return std::sin(y); }
+    *dz = 1.0;
+    return y;
+}
+
+// env.cost(x, u, u_last, a) (cartpole.py:99-105,112-127); identity features: J = I, j = 0.
 inline double cost(const trajopt_env_t& e, const double* x, const double* u, const double* u_last, double a) {
     const int n = e.dm_state, m = e.dm_act;
     double c = 0.;
@@ -229,9 +240,17 @@ inline double cost(const trajopt_env_t& e, const double* x, const double* u, con
     }
     if (a != 0.) {  // Python `if a:` (cartpole.py:120): an exactly-zero weight drops the state cost
         double s = 0.;
-        for (int i = 0; i < n; ++i) {
-            const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
-            s += (y - e.goal[i]) * e.gw[i] * (y - e.goal[i]);
+        if (e.nb_features == 0) {
+            for (int i = 0; i < n; ++i) {
+                const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
+                s += (y - e.goal[i]) * e.gw[i] * (y - e.goal[i]);
+            }
+        } else {  // z = J(y) y + j = phi(y) at the evaluation point (cartpole.py:122-125)
+            for (int f = 0; f < e.nb_features; ++f) {
+                double dz;
+                const double z = feature(e, x, f, &dz);
+                s += (z - e.goal[f]) * e.gw[f] * (z - e.goal[f]);
+            }
         }
         c += a * s;
     }
@@ -252,12 +271,23 @@ inline void cost_derivatives(const trajopt_env_t& e, const double* x, const doub
         cu[j] = sc * 2. * e.uw[j] * d;
     }
     for (int i = 0; i < n; ++i) {
-        if (a != 0.) {
+        if (a != 0. && e.nb_features == 0) {
             const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
             Cxx[i + n * i] = sc * 2. * a * e.gw[i];
             cx[i] = sc * 2. * a * e.gw[i] * (y - e.goal[i]);
         } else {
             cx[i] = 0.;
+        }
+    }
+    if (a != 0. && e.nb_features != 0) {
+        // autograd sees z = J y + j with J, j constants (getval, cartpole.py:122-124):
+        // cx = 2a J'G(z - g), Cxx = 2a J'GJ, accumulated feature by feature (row f of J has one entry)
+        for (int f = 0; f < e.nb_features; ++f) {
+            const int i = e.features[f] & 0xff;
+            double dz;
+            const double z = feature(e, x, f, &dz);
+            cx[i] += sc * 2. * a * e.gw[f] * (z - e.goal[f]) * dz;
+            Cxx[i + n * i] += sc * 2. * a * e.gw[f] * dz * dz;
         }
     }
 }

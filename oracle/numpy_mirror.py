@@ -137,7 +137,8 @@ def _clip(x, lim):
 class Env:
     """Parameter bag with the reference's constants; `name` selects the vector field."""
 
-    def __init__(self, name, dt=None, uw=None, slew_rate=False, periodic=False, **kw):
+    def __init__(self, name, dt=None, uw=None, slew_rate=False, periodic=False, cartesian=False, **kw):
+        self.features = None
         inf = np.inf
         lqr_dt = 0.1
         if name in ("lqr_v1", "lqr_v2"):   # lqr_v1.py:10-37, lqr_v2.py:10-36: other constants, same affine model
@@ -199,6 +200,22 @@ class Env:
             self.angles = []
         else:
             raise KeyError(name)
+        if cartesian:   # the "...WithCartesianCost" classes, written out as the reference writes them
+            self.features = {
+                "pendulum": lambda x: np.array([np.cos(x[0]), np.sin(x[0]), x[1]]),
+                "cartpole": lambda x: np.array([x[0], np.cos(x[1]), np.sin(x[1]), x[2], x[3]]),
+                "double_cartpole": lambda x: np.array([x[0], np.cos(x[0]), np.sin(x[0]), np.cos(x[1]), np.sin(x[1]),
+                                                       x[2], x[3], x[4]]),   # double_cartpole.py:226-230, as written
+                "double_pendulum": lambda x: np.array([np.cos(x[0]), np.sin(x[0]), np.cos(x[1]), np.sin(x[1]),
+                                                       x[2], x[3]]),
+            }[name]
+            self.g, self.gw = {
+                "pendulum": (np.array([1., 0., 0.]), np.array([1e4, 1e4, 1e0])),
+                "cartpole": (np.array([0., 1., 0., 0., 0.]), np.array([1e1, 1e4, 1e4, 1e0, 1e0])),
+                "double_cartpole": (np.array([0., 1., 0., 1., 0., 0., 0., 0.]),
+                                    np.array([1e1, 1e4, 1e4, 1e4, 1e4, 1e0, 1e0, 1e0])),
+                "double_pendulum": (np.array([1., 0., 1., 0., 0., 0.]), np.array([1e4, 1e4, 1e4, 1e4, 1e0, 1e0])),
+            }[name]
         if dt is not None:
             self.dt = dt
         if uw is not None:
@@ -286,7 +303,8 @@ class Env:
         k4 = self.f(x + dt * k3, _u)
         return _clip(x + dt / 6. * (k1 + 2. * k2 + 2. * k3 + k4), self.xmax)
 
-    def cost(self, x, u, u_last, a):
+    def cost(self, x, u, u_last, a, frozen_at=None):
+        """frozen_at: the point whose feature Jacobian is used (getval(y), cartpole.py:122-124); None = x itself."""
         x, u, u_last = np.asarray(x, dtype=float), np.atleast_1d(u).astype(float), np.atleast_1d(u_last).astype(float)
         d = (u - u_last) if self.slew_rate else u
         c = d @ np.diag(self.uw) @ d
@@ -295,7 +313,14 @@ class Env:
             if self.periodic:
                 for i in self.angles:
                     y[i] = ((x[i] + np.pi) % (2. * np.pi)) - np.pi
-            c += a * (y - self.g) @ np.diag(self.gw) @ (y - self.g)
+            if self.features is not None:
+                y0 = y if frozen_at is None else np.asarray(frozen_at, dtype=float)
+                hh = 1e-30   # complex-step Jacobian of the features at the frozen point
+                J = np.stack([self.features(y0 + 1j * hh * np.eye(self.n)[k]).imag / hh for k in range(self.n)], axis=1)
+                z = J @ y + (self.features(y0) - J @ y0)
+            else:
+                z = y
+            c += a * (z - self.g) @ np.diag(self.gw) @ (z - self.g)
         return self.dt * c if self.cost_times_dt else c
 
     # derivatives
@@ -321,7 +346,7 @@ class Env:
         n, m = self.n, self.m
 
         def c(z):
-            return self.cost(z[:n], z[n:], u_last, a)
+            return self.cost(z[:n], z[n:], u_last, a, frozen_at=x if self.features is not None else None)
 
         N = n + m
         g, H = np.zeros(N), np.zeros((N, N))

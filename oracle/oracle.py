@@ -25,6 +25,7 @@ class EnvStruct(C.Structure):
     """Mirror of include/trajopt_env.h::trajopt_env_t."""
     _fields_ = [("model", C.c_int32), ("dm_state", C.c_int32), ("dm_act", C.c_int32),
                 ("slew_rate", C.c_int32), ("periodic", C.c_int32), ("cost_times_dt", C.c_int32),
+                ("nb_features", C.c_int32), ("features", C.c_int32 * MAX_STATE), ("reserved0", C.c_int32),
                 ("dt", C.c_double),
                 ("umax", C.c_double * MAX_ACT), ("xmax", C.c_double * MAX_STATE),
                 ("goal", C.c_double * MAX_STATE), ("gw", C.c_double * MAX_STATE),
@@ -66,7 +67,20 @@ def _p(a):
 
 
 # ---- env parameter sets, constants cited from the reference -----------------------------------
-def make_env(name, dt=None, uw=None, slew_rate=False, periodic=False, **kw):
+# "...WithCartesianCost" variants: (features as (kind, state) with kind 0 = id, 1 = cos, 2 = sin; goal; weights)
+#   pendulum.py:152-162, cartpole.py:150-166, double_cartpole.py:210-230 (which takes cos / sin of x[0], x[1] and
+#   drops x[5] - kept as written), double_pendulum.py:178-194
+CARTESIAN = {
+    "pendulum": ([(1, 0), (2, 0), (0, 1)], [1., 0., 0.], [1e4, 1e4, 1e0]),
+    "cartpole": ([(0, 0), (1, 1), (2, 1), (0, 2), (0, 3)], [0., 1., 0., 0., 0.], [1e1, 1e4, 1e4, 1e0, 1e0]),
+    "double_cartpole": ([(0, 0), (1, 0), (2, 0), (1, 1), (2, 1), (0, 2), (0, 3), (0, 4)],
+                        [0., 1., 0., 1., 0., 0., 0., 0.], [1e1, 1e4, 1e4, 1e4, 1e4, 1e0, 1e0, 1e0]),
+    "double_pendulum": ([(1, 0), (2, 0), (1, 1), (2, 1), (0, 2), (0, 3)], [1., 0., 1., 0., 0., 0.],
+                        [1e4, 1e4, 1e4, 1e4, 1e0, 1e0]),
+}
+
+
+def make_env(name, dt=None, uw=None, slew_rate=False, periodic=False, cartesian=False, **kw):
     e = EnvStruct()
     inf = float("inf")
 
@@ -145,6 +159,14 @@ def make_env(name, dt=None, uw=None, slew_rate=False, periodic=False, **kw):
         fill(e.phys, [9.81, 0.5, 0.25, 3.9e-3, 3.9e-3, 7.5e-3, 1.6e-2])
     else:
         raise KeyError(name)
+    if cartesian:
+        feats, g, gw = CARTESIAN[name]
+        e.nb_features = len(feats)
+        for f, (kind, i) in enumerate(feats):
+            e.features[f] = (kind << 8) | i
+        for k in range(MAX_STATE):
+            e.goal[k] = e.gw[k] = 0.0
+        fill(e.goal, g); fill(e.gw, gw)
     e.slew_rate = int(bool(slew_rate))
     return e
 

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared_functions():
         assert hasattr(L, name), name
-    assert L.trajopt_abi_version() == _lib.ABI_VERSION == 2
+    assert L.trajopt_abi_version() == _lib.ABI_VERSION == 3
     assert L.trajopt_error_string(-4).decode().startswith("no HIP device")
 
 

@@ -56,6 +56,12 @@ def test_env_registry_and_struct():
         assert type(e) is type(envs.make(name))
         assert e.unwrapped is e and e.action_space.shape == (e.dm_act,) and e.observation_space.shape == (e.dm_state,)
         assert bytes(e.struct()) == bytes(O.make_env(name))
+    for name, ref_id in (("pendulum", "Pendulum-TO-v1"), ("cartpole", "Cartpole-TO-v1"),
+                         ("double_cartpole", "DoubleCartpole-TO-v1"), ("double_pendulum", "DoublePendulum-TO-v1")):
+        e = envs.make(ref_id)                  # the ...WithCartesianCost classes
+        assert type(e) is type(envs.make(name, cartesian=True)) and e.features is not None
+        assert bytes(e.struct()) == bytes(O.make_env(name, cartesian=True))
+        assert e.struct().nb_features == len(e.g) == len(e.gw)
     e = envs.make("Cartpole-TO-v0")
     e.unwrapped.dt = 0.02                      # the reference's scripts mutate attributes after make()
     e.unwrapped.uw = 1e-5 * np.ones(1)

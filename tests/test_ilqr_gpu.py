@@ -9,7 +9,13 @@ from tests.util import TOL, assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
-ENVS = ["pendulum", "cartpole", "double_cartpole", "quadrotor", "lqr", "double_pendulum", "robot", "lqr_v1", "lqr_v2"]
+ENVS = ["pendulum", "cartpole", "double_cartpole", "quadrotor", "lqr", "double_pendulum", "robot", "lqr_v1", "lqr_v2",
+        # the ...WithCartesianCost classes: nonlinear cost features, frozen-Jacobian derivatives
+        "pendulum_cartesian", "cartpole_cartesian", "double_cartpole_cartesian", "double_pendulum_cartesian"]
+
+
+def _base(name):
+    return name[:-len("_cartesian")] if name.endswith("_cartesian") else name
 
 
 def _pair(name, **kw):
@@ -18,6 +24,8 @@ def _pair(name, **kw):
     from trajopt_amd import envs
     pe = envs.make(name, **kw)
     okw = dict(kw)
+    if name != _base(name):
+        name, okw["cartesian"] = _base(name), True
     if "uw" in okw:
         okw["uw"] = list(np.asarray(okw["uw"], dtype=float) * np.ones(pe.dm_act))
     oe = O.make_env(name, **okw)
@@ -26,7 +34,7 @@ def _pair(name, **kw):
 
 def _rand_state(name, rng, N):
     n = {"pendulum": 2, "cartpole": 4, "double_cartpole": 6, "quadrotor": 12, "lqr": 2, "double_pendulum": 4, "robot": 4,
-         "lqr_v1": 2, "lqr_v2": 2}[name]
+         "lqr_v1": 2, "lqr_v2": 2}[_base(name)]
     x = rng.standard_normal((N, n))
     if name == "quadrotor":
         x[:, 3:6] *= 0.3  # keep away from the Euler singularity
@@ -35,7 +43,7 @@ def _rand_state(name, rng, N):
 
 def test_env_struct_matches_oracle_struct():
     for name in ENVS:
-        for kw in ({}, dict(dt=0.05, uw=[1e-2] * {"quadrotor": 4, "double_pendulum": 2, "robot": 2}.get(name, 1), slew_rate=True, periodic=True)):
+        for kw in ({}, dict(dt=0.05, uw=[1e-2] * {"quadrotor": 4, "double_pendulum": 2, "robot": 2}.get(_base(name), 1), slew_rate=True, periodic=True)):
             pe, oe = _pair(name, **kw)
             assert bytes(pe.struct()) == bytes(oe), name
 
@@ -45,7 +53,7 @@ def test_env_struct_matches_oracle_struct():
 def test_env_step_matches_oracle(oracle, name, layout):
     import torch
     from trajopt_amd import _lib, layout as L
-    pe, oe = _pair(name, slew_rate=True, periodic=(name in ("pendulum", "cartpole", "double_cartpole", "double_pendulum")))
+    pe, oe = _pair(name, slew_rate=True, periodic=(_base(name) in ("pendulum", "cartpole", "double_cartpole", "double_pendulum")))
     rng = np.random.default_rng(3)
     N = 130
     n, m = pe.dm_state, pe.dm_act
@@ -137,7 +145,7 @@ def test_quadratize_matches_oracle(oracle, name, layout, convention):
     slew-rate cost, periodic wrap and zero weights."""
     import torch
     from trajopt_amd import _lib, layout as L
-    periodic = name in ("pendulum", "cartpole", "double_cartpole")
+    periodic = _base(name) in ("pendulum", "cartpole", "double_cartpole")
     pe, oe = _pair(name, slew_rate=True, periodic=periodic)
     rng = np.random.default_rng(5)
     N, T = 66, 12
@@ -192,6 +200,9 @@ def _solve_pair(oracle, name, N, T, iters, seed=1337, scale=1e-2, gains_layout=N
     ("robot", 50, 4, dict()),                                 # 8f.3: dx = 4, du = 2, RK4 by -dt, cost x dt
     ("lqr_v1", 60, 4, dict()),
     ("lqr_v2", 60, 4, dict()),
+    ("cartpole_cartesian", 60, 4, dict(dt=0.02, uw=[1e-5])),  # 8f.3: Cartesian cost - dense Cxx, no structured cost
+    ("pendulum_cartesian", 80, 4, dict(dt=0.05, uw=[1e-5])),
+    ("double_cartpole_cartesian", 40, 3, dict(dt=0.01, uw=[1e-5])),
     ("cartpole", 40, 4, dict(dt=0.02, uw=[1e-5], gains_layout=0)),          # forced PROBLEM_MAJOR gains group
     ("double_cartpole", 30, 3, dict(dt=0.01, uw=[1e-5], gains_layout=0)),
     ("quadrotor", 30, 2, dict(dt=0.02, gains_layout=1)),                    # forced PROBLEM_MINOR

@@ -368,3 +368,26 @@ def test_gps_closed_forms(oracle, mirror):
         oracle.gps_augment_cost(*aa[:8], bad, q["alpha"], n, m, T)
     with pytest.raises(np.linalg.LinAlgError):
         oracle.gps_kl_divergence(K, kff, sg, K, kff, bad, fw[0], fw[1], n, m, T)
+
+
+@pytest.mark.parametrize("name", ["pendulum", "cartpole", "double_cartpole", "double_pendulum"])
+def test_cartesian_cost_and_frozen_jacobian_derivatives(oracle, mirror, name):
+    """The ...WithCartesianCost classes (e.g. cartpole.py:112-127,150-166): the cost is evaluated on z = J(y) y + j
+    = phi(y) and differentiated with J, j held constant (getval) - the mirror builds exactly that quadratic with a
+    complex-step J and differentiates it by central differences; the oracle has the closed forms."""
+    e, me = oracle.make_env(name, cartesian=True, dt=0.02), mirror.Env(name, cartesian=True, dt=0.02)
+    rng = np.random.default_rng(21)
+    T = 5
+    xref, uref = rng.standard_normal((me.n, T + 1)), rng.standard_normal((me.m, T))
+    w = np.array([1.0, 0.7, 0.0, 1.3, 0.9, 2.0])
+    q = oracle.quadratize(e, T, xref, uref, w)
+    for t in range(T + 1):
+        u = uref[:, t] if t < T else np.zeros(me.m)
+        assert oracle.env_cost(e, xref[:, t], u, u, w[t]) == pytest.approx(me.cost(xref[:, t], u, u, w[t]), rel=1e-12)
+        Cxx, cx, Cuu, cu, Cxu = me.cost_derivatives_fd(xref[:, t], u, u, w[t], h=1e-1)
+        sc = max(np.abs(Cxx).max(), 1.0)
+        np.testing.assert_allclose(q["Cxx"][..., t], Cxx, rtol=0, atol=1e-8 * sc)
+        np.testing.assert_allclose(q["cx"][:, t], cx, rtol=0, atol=1e-9 * sc)
+        np.testing.assert_allclose(q["Cxu"][..., t], Cxu, rtol=0, atol=1e-8 * sc)
+        assert np.count_nonzero(q["Cxx"][..., t] - np.diag(np.diag(q["Cxx"][..., t]))) == 0   # one state per feature
+    assert np.all(q["Cxx"][..., 2] == 0.0) and np.all(q["cx"][:, 2] == 0.0)     # `if a:` with a zero weight

@@ -13,7 +13,7 @@ SO_PATH = os.path.join(_HERE, "libtrajopt_amd.so")
 LAYOUT_PROBLEM_MAJOR = 0
 LAYOUT_PROBLEM_MINOR = 1
 MAX_ALPHAS = 16
-ABI_VERSION = 2          # include/trajopt_amd.h::TRAJOPT_ABI_VERSION
+ABI_VERSION = 3          # include/trajopt_amd.h::TRAJOPT_ABI_VERSION
 MAX_STATE, MAX_ACT = 12, 4
 
 ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR, ENV_DOUBLE_PENDULUM, ENV_ROBOT = 1, 2, 3, 4, 5, 6, 7
@@ -27,6 +27,7 @@ class EnvStruct(C.Structure):
     """include/trajopt_env.h::trajopt_env_t"""
     _fields_ = [("model", C.c_int32), ("dm_state", C.c_int32), ("dm_act", C.c_int32),
                 ("slew_rate", C.c_int32), ("periodic", C.c_int32), ("cost_times_dt", C.c_int32),
+                ("nb_features", C.c_int32), ("features", C.c_int32 * MAX_STATE), ("reserved0", C.c_int32),
                 ("dt", C.c_double),
                 ("umax", C.c_double * MAX_ACT), ("xmax", C.c_double * MAX_STATE),
                 ("goal", C.c_double * MAX_STATE), ("gw", C.c_double * MAX_STATE),

@@ -302,10 +302,10 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
     const bool gminor = GL == TRAJOPT_LAYOUT_PROBLEM_MINOR;
     io.g_norm = ws->g_norm; io.active = ws->active;
     io.uref = gminor ? ws->uref : nullptr;  // fused gradient norm needs kff and uref in one layout
-    // Structured cost: every env model has identity features, so Cxx = w[t] 2 diag(gw), Cuu = 2 diag(uw), Cxu = 0
+    // Structured cost: with identity features (not the ...WithCartesianCost envs) Cxx = w[t] 2 diag(gw), Cuu = 2 diag(uw), Cxu = 0
     // (quadratize.hip); when the backward kernel of this shape can form them itself they are neither written by the
     // quadratisation nor read back - 168 of the 368 bytes a cartpole step moves through HBM each way.
-    const bool structured = trajopt_backward_supports_structured_cost(n, m, T, NP, GL) != 0;
+    const bool structured = env->nb_features == 0 && trajopt_backward_supports_structured_cost(n, m, T, NP, GL) != 0;
     if (structured) {
         const double sc = env->cost_times_dt ? env->dt : 1.0;
         io.cost_w = ws->weighting;

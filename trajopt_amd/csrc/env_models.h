@@ -375,7 +375,43 @@ __device__ __forceinline__ double env_cost_plain(const trajopt_env_t& e, const d
     return c;
 }
 
-// env.cost(x, u, u_last, a) with identity features (cartpole.py:112-127; LQR: lqr_v0.py:89-94).
+// State cost (z - g)'G(z - g) with the features z = phi(y) of trajopt_env_t::features (cartpole.py:119-125,161-166)
+// and, when DERIV, its frozen-Jacobian derivatives per state: gx[i] = sum_f gw_f (z_f - g_f) dz_f/dy_i and
+// hxx[i] = sum_f gw_f (dz_f/dy_i)^2 (every feature depends on ONE state, so J'GJ is diagonal); the caller scales
+// them by 2 a.  State arrays are only indexed statically: the feature list is scanned per state.
+template <int N, bool DERIV>
+__device__ __forceinline__ double feature_cost(const trajopt_env_t& e, const double (&x)[N], int n, double (&gx)[N],
+                                               double (&hxx)[N]) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        gx[i] = 0.0;
+        hxx[i] = 0.0;
+        if (i < n) {
+            const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
+            double sn, cs;
+            sincos_g(y, sn, cs);
+#pragma unroll
+            for (int f = 0; f < TRAJOPT_ENV_MAX_STATE; ++f) {
+                const int code = e.features[f];
+                if (f < e.nb_features && (code & 0xff) == i) {
+                    const int kind = code >> 8;
+                    const double z = kind == TRAJOPT_FEAT_ID ? y : (kind == TRAJOPT_FEAT_COS ? cs : sn);
+                    const double dz = kind == TRAJOPT_FEAT_ID ? 1.0 : (kind == TRAJOPT_FEAT_COS ? -sn : cs);
+                    const double r = z - e.goal[f];
+                    s = fma(r * e.gw[f], r, s);
+                    if (DERIV) {
+                        gx[i] = fma(e.gw[f] * r, dz, gx[i]);
+                        hxx[i] = fma(e.gw[f] * dz, dz, hxx[i]);
+                    }
+                }
+            }
+        }
+    }
+    return s;
+}
+
+// env.cost(x, u, u_last, a) (cartpole.py:112-127; LQR: lqr_v0.py:89-94).
 // N, M are array capacities; n, m the live dimensions.
 template <int N, int M>
 __device__ __forceinline__ double env_cost(const trajopt_env_t& e, const double (&x)[N], const double (&u)[M],
@@ -389,13 +425,18 @@ __device__ __forceinline__ double env_cost(const trajopt_env_t& e, const double 
         }
     if (a != 0.0) {  // Python `if a:` drops the state cost for an exactly-zero weight
         double s = 0.0;
+        if (e.nb_features == 0) {
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-            if (i < n) {
-                const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
-                const double r = y - e.goal[i];
-                s = fma(r * e.gw[i], r, s);
-            }
+            for (int i = 0; i < N; ++i)
+                if (i < n) {
+                    const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
+                    const double r = y - e.goal[i];
+                    s = fma(r * e.gw[i], r, s);
+                }
+        } else {
+            double cx_unused[N], cxx_unused[N];
+            s = feature_cost<N, false>(e, x, n, cx_unused, cxx_unused);
+        }
         c = fma(a, s, c);
     }
     return e.cost_times_dt ? e.dt * c : c;

@@ -135,14 +135,21 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
         const double sc = e.cost_times_dt ? e.dt : 1.0;
         const size_t Enn1 = (size_t)n * n * (T + 1), Emm1 = (size_t)m * m * (T + 1), Enm1 = (size_t)n * m * (T + 1),
                      Em1 = (size_t)m * (T + 1);
+        double fgx[N], fhxx[N];
+        if (e.nb_features != 0) feature_cost<N, true>(e, x, n, fgx, fhxx);
 #pragma unroll
         for (int i = 0; i < N; ++i)
             if (i < n) {
                 double g = 0.0, h = 0.0;
                 if (w != 0.0) {
-                    const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
-                    h = w * (sc * 2.0 * e.gw[i]);  // = w[t] * cost_gxx[i], the structured form the backward pass can take
-                    g = h * (y - e.goal[i]);
+                    if (e.nb_features == 0) {
+                        const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
+                        h = w * (sc * 2.0 * e.gw[i]);  // = w[t] * cost_gxx[i], the structured form the backward pass can take
+                        g = h * (y - e.goal[i]);
+                    } else {   // frozen feature Jacobian (cartpole.py:122-124): Gauss-Newton
+                        h = w * (sc * 2.0) * fhxx[i];
+                        g = w * (sc * 2.0) * fgx[i];
+                    }
                 }
                 a.cx[qi<OMINOR>((size_t)n * t + i, En1, p, NP)] = g;
                 if (a.Cxx) {  // NULL: the backward pass forms Cxx, Cuu, Cxu itself (trajopt_backward_io_t::cost_w)

@@ -83,6 +83,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         ev.slew_rate = a.env.slew_rate;  // flags stay wave-uniform so that their branches stay scalar
         ev.periodic = a.env.periodic;
         ev.cost_times_dt = a.env.cost_times_dt;
+        ev.nb_features = a.env.nb_features;
+#pragma unroll
+        for (int f = 0; f < TRAJOPT_ENV_MAX_STATE; ++f) ev.features[f] = a.env.features[f];
         // x + 0.0 is an arithmetic result, i.e. canonical: fmin / fmax against it need no v_max(x, x) quieting per use
 #pragma unroll
         for (int j = 0; j < M; ++j) ev.umax[j] += 0.0;
@@ -297,7 +300,7 @@ struct RolloutLaunch {
         const double kbytes = kmi ? (double)SYS::N * SYS::M * (double)a.NP * 8.0
                                   : (double)a.NP * SYS::N * SYS::M * (double)a.T * 8.0;
         const bool fast = SYS::kStatic && a.state && a.action && !a.cost && !a.env.slew_rate && a.env.periodic == 0 &&
-                          !a.env.cost_times_dt && a.T > 0 && kbytes + (double)a.NP * 8.0 < 4294967296.0;
+                          !a.env.cost_times_dt && a.env.nb_features == 0 && a.T > 0 && kbytes + (double)a.NP * 8.0 < 4294967296.0;
         if constexpr (SYS::kStatic) {
             if (mi && fast) {
                 if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true>), grid, block, 0, st, a);

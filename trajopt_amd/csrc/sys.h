@@ -82,6 +82,9 @@ struct SysLqr {
 // Run `fn.template operator()<SYS>()` for the env's model; returns false for an unknown model.
 template <class F>
 inline bool dispatch_model(const trajopt_env_t& e, F&& fn) {
+    if (e.nb_features < 0 || e.nb_features > TRAJOPT_ENV_MAX_STATE) return false;
+    for (int f = 0; f < e.nb_features; ++f)
+        if ((e.features[f] & 0xff) >= e.dm_state || (e.features[f] >> 8) > TRAJOPT_FEAT_SIN || e.features[f] < 0) return false;
     switch (e.model) {
         case TRAJOPT_ENV_PENDULUM:
             if (e.dm_state != 2 || e.dm_act != 1) return false;

@@ -33,6 +33,7 @@ class Env:
     model = None
     phys = ()
     angles = ()          # indices wrapped by the cost when `periodic` (e.g. cartpole.py:121-122)
+    features = None      # [(kind, state)], kind 0 = id, 1 = cos, 2 = sin: the ...WithCartesianCost classes; None = identity
     cost_times_dt = False
 
     def __init__(self):
@@ -105,8 +106,16 @@ class Env:
 
         fill(e.umax, self.umax, m)
         fill(e.xmax, self.xmax, n)
-        fill(e.goal, self.g, n)
-        fill(e.gw, self.gw, n)
+        nf = n
+        if self.features is not None:
+            nf = len(self.features)
+            if nf > MAX_STATE:
+                raise _lib.TrajoptError("%d cost features exceed %d" % (nf, MAX_STATE))
+            e.nb_features = nf
+            for f, (kind, i) in enumerate(self.features):
+                e.features[f] = (int(kind) << 8) | int(i)
+        fill(e.goal, self.g, nf)
+        fill(e.gw, self.gw, nf)
         fill(e.uw, self.uw, m)
         for i, v in enumerate(self.phys):
             e.phys[i] = float(v)
@@ -211,6 +220,44 @@ class DoublePendulum(Env):
         super().__init__()
 
 
+class PendulumWithCartesianCost(Pendulum):
+    """/root/reference/trajopt/envs/pendulum/pendulum.py:152-162: cost on [cos th, sin th, dth]."""
+    features = ((1, 0), (2, 0), (0, 1))
+
+    def __init__(self):
+        super().__init__()
+        self.g, self.gw = np.array([1., 0., 0.]), np.array([1e4, 1e4, 1e0])
+
+
+class CartpoleWithCartesianCost(Cartpole):
+    """/root/reference/trajopt/envs/cartpole/cartpole.py:150-166: cost on [x, cos th, sin th, dx, dth]."""
+    features = ((0, 0), (1, 1), (2, 1), (0, 2), (0, 3))
+
+    def __init__(self):
+        super().__init__()
+        self.g, self.gw = np.array([0., 1., 0., 0., 0.]), np.array([1e1, 1e4, 1e4, 1e0, 1e0])
+
+
+class DoubleCartpoleWithCartesianCost(DoubleCartpole):
+    """/root/reference/trajopt/envs/double_cartpole/double_cartpole.py:210-230.  Its feature map reads
+    [x0, cos x0, sin x0, cos x1, sin x1, x2, x3, x4] - one index short of its own comment, x5 unused - kept as written."""
+    features = ((0, 0), (1, 0), (2, 0), (1, 1), (2, 1), (0, 2), (0, 3), (0, 4))
+
+    def __init__(self):
+        super().__init__()
+        self.g = np.array([0., 1., 0., 1., 0., 0., 0., 0.])
+        self.gw = np.array([1e1, 1e4, 1e4, 1e4, 1e4, 1e0, 1e0, 1e0])
+
+
+class DoublePendulumWithCartesianCost(DoublePendulum):
+    """/root/reference/trajopt/envs/double_pendulum/double_pendulum.py:178-194."""
+    features = ((1, 0), (2, 0), (1, 1), (2, 1), (0, 2), (0, 3))
+
+    def __init__(self):
+        super().__init__()
+        self.g, self.gw = np.array([1., 0., 1., 0., 0., 0.]), np.array([1e4, 1e4, 1e4, 1e4, 1e0, 1e0])
+
+
 class LQRv0(Env):
     """/root/reference/trajopt/envs/lqr/lqr_v0.py:8-114: xn = A x + B clip(u) + c, cost scaled by dt.
     A, B, c, g, gw, uw may be replaced (any dx <= 12, du <= 4) for the time-invariant LQ known-answer cases."""
@@ -297,15 +344,22 @@ _REGISTRY = {
     # the reference's gym ids (/root/reference/trajopt/__init__.py:3-97) for the envs in scope
     "Pendulum-TO-v0": Pendulum, "Cartpole-TO-v0": Cartpole, "DoubleCartpole-TO-v0": DoubleCartpole,
     "LQR-TO-v0": LQRv0, "DoublePendulum-TO-v0": DoublePendulum, "double_pendulum": DoublePendulum,
+    "Pendulum-TO-v1": PendulumWithCartesianCost, "Cartpole-TO-v1": CartpoleWithCartesianCost,
+    "DoubleCartpole-TO-v1": DoubleCartpoleWithCartesianCost, "DoublePendulum-TO-v1": DoublePendulumWithCartesianCost,
+    "pendulum_cartesian": PendulumWithCartesianCost, "cartpole_cartesian": CartpoleWithCartesianCost,
+    "double_cartpole_cartesian": DoubleCartpoleWithCartesianCost,
+    "double_pendulum_cartesian": DoublePendulumWithCartesianCost,
     "LQR-TO-v1": LQRv1, "LQR-TO-v2": LQRv2, "Robot-TO-v0": Robot, "lqr_v1": LQRv1, "lqr_v2": LQRv2, "robot": Robot,
     "pendulum": Pendulum, "cartpole": Cartpole, "double_cartpole": DoubleCartpole, "lqr": LQRv0,
     "quadrotor": Quadrotor, "Quadrotor-TO-v0": Quadrotor,
 }
 
 
-def make(name, dt=None, uw=None, slew_rate=None, periodic=None, **kw):
+def make(name, dt=None, uw=None, slew_rate=None, periodic=None, cartesian=False, **kw):
     """gym.make stand-in: `make('Cartpole-TO-v0')`; keyword overrides are set as attributes afterwards,
     the way the reference's scripts do (examples/ilqr/mpc/pendulum.py:12-13)."""
+    if cartesian:
+        name = name + "_cartesian"
     if name not in _REGISTRY:
         raise KeyError("unknown env %r (in scope: %s)" % (name, sorted(_REGISTRY)))
     env = _REGISTRY[name](**kw)
