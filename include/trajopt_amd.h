@@ -224,6 +224,37 @@ int trajopt_gps_quad_expectation_host(const double* mu_host, const double* sigma
                                       const double* q_host, double q0, int dm_state, double* result);
 
 /* ------------------------------------------------------------------------------------------------
+ * SURVEY 8f.4.  Belief-space iLQR backward pass: replaces trajopt.bspilqr.core.backward_pass,
+ * /root/reference/trajopt/bspilqr/src/util.cpp:83-204 (called at bspilqr/bspilqr.py:90-104).  b = dm_belief; the
+ * covariance channel has b*b entries: p, tau (b*b, .), T, X (b*b, b, .), U, Y (b*b, b*b, .), V, Z (b*b, dm_act, .).
+ * Q, q, p are read up to slice nb_steps, everything else up to nb_steps - 1.  dS starts at zero (uninitialised in
+ * the reference, :132).  tau_mode: what util.cpp:158's read of the not-yet-assigned tau.col(i) means -
+ * 0 = tau.col(i+1) (the evident intent, as :152,:155), 1 = zeros.  Shapes: b in {2, 4}, dm_act in {1, 2}.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct trajopt_bsp_backward_io {
+    const double* Q; const double* q; const double* R; const double* r; const double* P; const double* p;
+    const double* F; const double* G; const double* T; const double* U; const double* V;
+    const double* X; const double* Y; const double* Z;
+    const double* lmbda;   /* [nb_problems] */
+    double* S; double* s; double* tau;
+    double* dS;            /* (2,) per problem */
+    double* K; double* kff;
+    int32_t* diverge;      /* [nb_problems]: -1 = completed, else the failing time index (:170-173) */
+} trajopt_bsp_backward_io_t;
+
+int trajopt_bspilqr_backward_supported(int dm_belief, int dm_act);
+int trajopt_bspilqr_backward_pass_batched(const trajopt_bsp_backward_io_t* io, int reg, int tau_mode, int dm_belief,
+                                          int dm_act, int nb_steps, int64_t nb_problems, int layout, void* stream);
+int trajopt_bspilqr_backward_pass_host(const double* Q_host, const double* q_host, const double* R_host,
+                                       const double* r_host, const double* P_host, const double* p_host,
+                                       const double* F_host, const double* G_host, const double* T_host,
+                                       const double* U_host, const double* V_host, const double* X_host,
+                                       const double* Y_host, const double* Z_host, double lmbda, int reg,
+                                       int tau_mode, int dm_belief, int dm_act, int nb_steps, double* S_host,
+                                       double* s_host, double* tau_host, double* dS_host, double* K_host,
+                                       double* kff_host, int* diverge, int* failed);
+
+/* ------------------------------------------------------------------------------------------------
  * A8.  Env model evaluated on the device: xn = env.dynamics(x, u), c = env.cost(x, u, u_last, a)
  * (e.g. cartpole.py:62-97,112-127).  x (n, N), u (m, N), PROBLEM_MINOR or MAJOR per `layout`.
  * Either output may be NULL.

@@ -504,3 +504,33 @@ def gps_forward_pass(mu_x0, sigma_x0, A, B, c, sigma_dyn, K, kff, sigma_ctl, n, 
     mu_xu[:n, T] = mu_x[:, T]
     sigma_xu[:n, :n, T] = sigma_x[..., T]
     return mu_x, sigma_x, mu_u, sigma_u, mu_xu, sigma_xu
+
+
+def bsp_backward_pass(Q, q, R, r, P, p, F, G, T_, U, V, X, Y, Z, lmbda, reg, b, m, T, tau_mode=0):
+    """bspilqr/src/util.cpp:83-204 with np.linalg.inv; tau_mode as in oracle/bsp_oracle.hpp.  -> dict."""
+    S, s, tau = np.zeros((b, b, T + 1)), np.zeros((b, T + 1)), np.zeros((b * b, T + 1))
+    K, kff, dS, diverge = np.zeros((m, b, T)), np.zeros((m, T)), np.zeros(2), -1
+    S[..., T], s[:, T], tau[:, T] = Q[..., T], q[:, T], p[:, T]
+    for i in range(T - 1, -1, -1):
+        Sn, sn, tn = S[..., i + 1], s[:, i + 1], tau[:, i + 1]
+        vS = Sn.flatten(order="F")
+        Cm = Q[..., i] + F[..., i].T @ Sn @ F[..., i]
+        D = R[..., i] + G[..., i].T @ Sn @ G[..., i]
+        E = (P[..., i] + F[..., i].T @ Sn @ G[..., i]).T
+        c = q[:, i] + F[..., i].T @ sn + T_[..., i].T @ tn + 0.5 * X[..., i].T @ vS
+        d = r[:, i] + G[..., i].T @ sn + V[..., i].T @ tn + 0.5 * Z[..., i].T @ vS
+        e = p[:, i] + (U[..., i].T @ tn if tau_mode == 0 else 0.0) + 0.5 * Y[..., i].T @ vS
+        Sreg = Sn + (lmbda * np.eye(b) if reg == 2 else 0.0)
+        Ereg = (P[..., i] + F[..., i].T @ Sreg @ G[..., i]).T
+        Dreg = R[..., i] + G[..., i].T @ Sreg @ G[..., i] + (lmbda * np.eye(m) if reg == 1 else 0.0)
+        if not arma_is_sympd(Dreg):
+            diverge = i
+            break
+        Dinv = np.linalg.inv(Dreg)
+        K[..., i], kff[:, i] = -Dinv @ Ereg, -Dinv @ d
+        dS += np.array([kff[:, i] @ d, 0.5 * kff[:, i] @ D @ kff[:, i]])
+        tau[:, i] = e
+        s[:, i] = c + K[..., i].T @ D @ kff[:, i] + K[..., i].T @ d + E.T @ kff[:, i]
+        Si = Cm + K[..., i].T @ D @ K[..., i] + K[..., i].T @ E + E.T @ K[..., i]
+        S[..., i] = 0.5 * (Si + Si.T)
+    return dict(S=S, s=s, tau=tau, dS=dS, K=K, kff=kff, diverge=diverge)

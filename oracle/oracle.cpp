@@ -11,6 +11,7 @@
 #include <vector>
 #include "ilqr_oracle.hpp"
 #include "gps_oracle.hpp"
+#include "bsp_oracle.hpp"
 
 using namespace oracle;
 
@@ -62,6 +63,19 @@ int oracle_gps_backward_pass(const double* Cxx, const double* cx, const double* 
                                               Quu, qx, qu, q0, V, v, v0, K, kff, sigma_ctl, failed);
     return gps_backward_pass<double>(Cxx, cx, Cuu, cu, Cxu, c0, A, B, c, sigma_dyn, alpha, n, m, T, Qxx, Qux, Quu, qx,
                                      qu, q0, V, v, v0, K, kff, sigma_ctl, failed);
+}
+
+// bspilqr/src/util.cpp:83-204; outputs zero-filled by the caller
+int oracle_bsp_backward_pass(const double* Q, const double* q, const double* R, const double* r, const double* P,
+                             const double* p, const double* F, const double* G, const double* T_, const double* U,
+                             const double* V, const double* X, const double* Y, const double* Z, double lmbda, int reg,
+                             int tau_mode, int b, int m, int T, int long_double, double* S, double* s, double* tau,
+                             double* dS, double* K, double* kff, int* failed) {
+    if (long_double)
+        return bsp_backward_pass<long double>(Q, q, R, r, P, p, F, G, T_, U, V, X, Y, Z, lmbda, reg, tau_mode, b, m, T,
+                                              S, s, tau, dS, K, kff, failed);
+    return bsp_backward_pass<double>(Q, q, R, r, P, p, F, G, T_, U, V, X, Y, Z, lmbda, reg, tau_mode, b, m, T, S, s, tau,
+                                     dS, K, kff, failed);
 }
 
 // gps/src/util.cpp:83-269

@@ -228,6 +228,23 @@ def gps_backward_pass(Cxx, cx, Cuu, cu, Cxu, c0, A, B, c, sigma_dyn, alpha, dm_s
     return (Qxx, Qux, Quu, qx, qu, q0, V, v, v0, K, kff, sg, int(rc)), bool(failed.value)
 
 
+BSP_ARGS = ("Q", "q", "R", "r", "P", "p", "F", "G", "T", "U", "V", "X", "Y", "Z")
+
+
+def bsp_backward_pass(Q, q, R, r, P, p, F, G, T_, U, V, X, Y, Z, lmbda, reg, dm_belief, dm_act, nb_steps, tau_mode=0,
+                      long_double=False):
+    """bspilqr/src/util.cpp:83-204.  Returns ((S, s, tau, dS, K, kff, diverge), failed)."""
+    b, m, T = dm_belief, dm_act, nb_steps
+    a = list(map(_f, (Q, q, R, r, P, p, F, G, T_, U, V, X, Y, Z)))
+    z = lambda *s: np.zeros(s, order="F")
+    S, s, tau, dS, K, kff = z(b, b, T + 1), z(b, T + 1), z(b * b, T + 1), z(2), z(m, b, T), z(m, T)
+    failed = C.c_int(0)
+    div = lib().oracle_bsp_backward_pass(*map(_p, a), C.c_double(float(lmbda)), int(reg), int(tau_mode), b, m, T,
+                                         int(long_double), _p(S), _p(s), _p(tau), _p(dS), _p(K), _p(kff),
+                                         C.byref(failed))
+    return (S, s, tau, dS, K, kff, int(div)), int(failed.value)
+
+
 def gps_kl_divergence(p_K, p_kff, p_sigma_ctl, q_K, q_kff, q_sigma_ctl, mu_x, sigma_x, dm_state, dm_act, nb_steps,
                       long_double=False):
     """gps/src/util.cpp:83-121 -> kl (T,)."""

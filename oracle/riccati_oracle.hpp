@@ -90,6 +90,13 @@ static M<S> mul3(const M<S>& A, const M<S>& B, const M<S>& C) {
     return mul(A, mul(B, C));
 }
 
+template <class S>
+static M<S> eye_m(int n) {
+    M<S> I(n, n);
+    for (int i = 0; i < n; ++i) I(i, i) = S(1);
+    return I;
+}
+
 // Plain (unpivoted) lower Cholesky in place; false if a pivot is not > 0 (NaN included).
 template <class S>
 static bool chol_lower(M<S>& X) {

@@ -391,3 +391,48 @@ def test_cartesian_cost_and_frozen_jacobian_derivatives(oracle, mirror, name):
         np.testing.assert_allclose(q["Cxu"][..., t], Cxu, rtol=0, atol=1e-8 * sc)
         assert np.count_nonzero(q["Cxx"][..., t] - np.diag(np.diag(q["Cxx"][..., t]))) == 0   # one state per feature
     assert np.all(q["Cxx"][..., 2] == 0.0) and np.all(q["cx"][:, 2] == 0.0)     # `if a:` with a zero weight
+
+
+# ---- the belief-space iLQR backward pass, bspilqr/src/util.cpp:83-204 --------------------------------
+@pytest.mark.parametrize("b,m,T", [(2, 2, 40), (4, 2, 25), (4, 1, 30), (3, 2, 12)])
+@pytest.mark.parametrize("reg", [1, 2])
+@pytest.mark.parametrize("tau_mode", [0, 1])
+def test_bsp_oracle_vs_mirror_vs_long_double(oracle, mirror, b, m, T, reg, tau_mode):
+    q = S.problem(S.bsp_inputs(b, m, T, 1, seed=400 + b), 0)
+    a = [q[k] for k in oracle.BSP_ARGS]
+    o, f = oracle.bsp_backward_pass(*a, 0.5, reg, b, m, T, tau_mode=tau_mode)
+    ld, _ = oracle.bsp_backward_pass(*a, 0.5, reg, b, m, T, tau_mode=tau_mode, long_double=True)
+    mi = mirror.bsp_backward_pass(*a, 0.5, reg, b, m, T, tau_mode=tau_mode)
+    assert not f and o[6] == 0 and mi["diverge"] == -1
+    for k, x, y in zip(("S", "s", "tau", "dS", "K", "kff"), o[:6], ld[:6]):
+        assert_close(x, y, "ld " + k, tol=1e-10)
+        assert_close(x, mi[k], "mirror " + k, tol=1e-10)
+
+
+def test_bsp_reduces_to_the_ilqr_pass_without_the_covariance_channel(oracle):
+    """T = U = V = X = Y = Z = 0: S, s, K, kff, dS are util.cpp:83-182's V, v, K, kff, dV of the same problem (the
+    two files share the recursion, bspilqr/src/util.cpp:148-188 vs ilqr/src/util.cpp:122-170), tau stays p."""
+    b, m, T = 4, 2, 30
+    q = S.problem(S.bsp_inputs(b, m, T, 1, seed=9, coupling=0.0), 0)
+    for reg in (1, 2):
+        o, f = oracle.bsp_backward_pass(*[q[k] for k in oracle.BSP_ARGS], 0.7, reg, b, m, T)
+        r, fr = oracle.backward_pass(q["Q"], q["q"], q["R"], q["r"], q["P"], q["F"], q["G"], 0.7, reg, b, m, T)
+        assert not f and not fr
+        for i, j, k in ((0, 5, "S"), (1, 6, "s"), (3, 7, "dS"), (4, 8, "K"), (5, 9, "kff")):
+            assert_close(o[i], r[j], k, tol=1e-11)
+        assert np.array_equal(o[2], q["p"])
+
+
+def test_bsp_divergence_and_tau_modes(oracle, mirror):
+    b, m, T = 2, 2, 15
+    q = S.problem(S.bsp_inputs(b, m, T, 1, seed=2, coupling=0.2), 0)
+    a = [q[k] for k in oracle.BSP_ARGS]
+    o0, _ = oracle.bsp_backward_pass(*a, 0.5, 1, b, m, T, tau_mode=0)
+    o1, _ = oracle.bsp_backward_pass(*a, 0.5, 1, b, m, T, tau_mode=1)
+    assert np.array_equal(o0[0], o1[0]) and np.array_equal(o0[4], o1[4])          # tau never feeds S or K ...
+    assert np.array_equal(o0[2][:, T - 1], o1[2][:, T - 1]) is False              # ... only itself, s and kff, via U
+    q["R"][:, :, 6] = -50.0 * np.eye(m)
+    a = [q[k] for k in oracle.BSP_ARGS]
+    o, f = oracle.bsp_backward_pass(*a, 0.5, 1, b, m, T)
+    assert f == 1 and o[6] == 6 and mirror.bsp_backward_pass(*a, 0.5, 1, b, m, T)["diverge"] == 6
+    assert np.all(o[4][..., :7] == 0.0) and np.all(o[0][..., :7] == 0.0) and np.any(o[0][..., 7] != 0.0)

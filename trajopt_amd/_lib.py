@@ -61,6 +61,13 @@ class GpsBackwardIO(C.Structure):
                  "Qxx", "Qux", "Quu", "qx", "qu", "q0", "V", "v", "v0", "K", "kff", "sigma_ctl", "diverge", "status")]
 
 
+class BspBackwardIO(C.Structure):
+    """include/trajopt_amd.h::trajopt_bsp_backward_io_t"""
+    _fields_ = [(k, _dp) for k in
+                ("Q", "q", "R", "r", "P", "p", "F", "G", "T", "U", "V", "X", "Y", "Z", "lmbda",
+                 "S", "s", "tau", "dS", "K", "kff", "diverge")]
+
+
 class ILQROptions(C.Structure):
     _fields_ = [("sched", LambdaSchedule), ("tolfun", C.c_double), ("tolgrad", C.c_double),
                 ("min_imp", C.c_double), ("reg", C.c_int32), ("nb_alphas", C.c_int32),
@@ -89,6 +96,7 @@ EXPORTS = (
     "trajopt_gps_forward_pass_batched", "trajopt_gps_augment_cost_batched", "trajopt_gps_kl_divergence_batched",
     "trajopt_gps_quad_expectation_batched", "trajopt_gps_forward_pass_host", "trajopt_gps_augment_cost_host",
     "trajopt_gps_kl_divergence_host", "trajopt_gps_quad_expectation_host",
+    "trajopt_bspilqr_backward_supported", "trajopt_bspilqr_backward_pass_batched", "trajopt_bspilqr_backward_pass_host",
     "trajopt_riccati_backward_pass_host", "trajopt_riccati_backward_pass_batched",
     "trajopt_env_step_batched", "trajopt_ilqr_forward_pass_batched", "trajopt_quadratize_batched",
     "trajopt_ilqr_init_rollout", "trajopt_ilqr_iterate", "trajopt_convert_layout",

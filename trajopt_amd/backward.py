@@ -5,7 +5,7 @@ Thin plumbing over the C ABI: torch only provides device memory and the current 
 import ctypes as C
 
 from . import _lib
-from ._lib import BackwardIO, GpsBackwardIO, LambdaSchedule, LAYOUT_PROBLEM_MAJOR, LAYOUT_PROBLEM_MINOR, check, dptr, lib, stream_ptr
+from ._lib import BackwardIO, BspBackwardIO, GpsBackwardIO, LambdaSchedule, LAYOUT_PROBLEM_MAJOR, LAYOUT_PROBLEM_MINOR, check, dptr, lib, stream_ptr
 from .layout import empty
 
 
@@ -206,3 +206,36 @@ def gps_quad_expectation(mu, sigma_s, Q, q, q0, dm_state, nb_problems, layout=LA
     check(lib().trajopt_gps_quad_expectation_batched(*map(dptr, (mu, sigma_s, Q, q, q0)), n, C.c_int64(N),
                                                      int(layout), dptr(out), stream_ptr()))
     return out
+
+
+def bsp_backward_pass(Q, q, R, r, P, p, F, G, T_, U, V, X, Y, Z, lmbda, reg, dm_belief, dm_act, nb_steps, nb_problems,
+                      layout=LAYOUT_PROBLEM_MINOR, tau_mode=0):
+    """Belief-space iLQR backward pass of /root/reference/trajopt/bspilqr/src/util.cpp:83-204 for a batch.
+    Device tensors in PROBLEM_MINOR; Q, q, p hold nb_steps + 1 slices, the others nb_steps (or more: a prefix is read);
+    lmbda is a [N] tensor.  Returns S, s, tau, dS (N, 2), K, kff, diverge (-1 = completed)."""
+    import torch
+    _lib.require_gpu()
+    b, m, T, N = dm_belief, dm_act, nb_steps, nb_problems
+    bb = b * b
+    for t, cnt, nm in ((Q, bb * (T + 1), "Q"), (q, b * (T + 1), "q"), (p, bb * (T + 1), "p")):
+        _chk(t, cnt * N, nm)
+    for t, per, nm in ((R, m * m, "R"), (r, m, "r"), (P, b * m, "P"), (F, bb, "F"), (G, b * m, "G"), (T_, bb * b, "T"),
+                       (U, bb * bb, "U"), (V, bb * m, "V"), (X, bb * b, "X"), (Y, bb * bb, "Y"), (Z, bb * m, "Z")):
+        if t.numel() < per * T * N:
+            raise ValueError("%s holds fewer than %d slices" % (nm, T))
+        _chk(t, t.numel(), nm)
+    _chk(lmbda, N, "lmbda")
+    dev = Q.device
+    o = dict(S=empty((N, b, b, T + 1), layout, dev, zero=True), s=empty((N, b, T + 1), layout, dev, zero=True),
+             tau=empty((N, bb, T + 1), layout, dev, zero=True), dS=empty((N, 2), layout, dev, zero=True),
+             K=empty((N, m, b, T), layout, dev, zero=True), kff=empty((N, m, T), layout, dev, zero=True),
+             diverge=torch.empty(N, dtype=torch.int32, device=dev))
+    io = BspBackwardIO()
+    for k, t in zip(("Q", "q", "R", "r", "P", "p", "F", "G", "T", "U", "V", "X", "Y", "Z", "lmbda"),
+                    (Q, q, R, r, P, p, F, G, T_, U, V, X, Y, Z, lmbda)):
+        setattr(io, k, dptr(t))
+    for k in ("S", "s", "tau", "dS", "K", "kff", "diverge"):
+        setattr(io, k, dptr(o[k]))
+    check(lib().trajopt_bspilqr_backward_pass_batched(C.byref(io), int(reg), int(tau_mode), b, m, T, C.c_int64(N),
+                                                      int(layout), stream_ptr()))
+    return o

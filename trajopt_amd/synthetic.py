@@ -58,3 +58,17 @@ def gps_inputs(n, m, T, N, seed=SEED):
     out["sigma_dyn"] = np.ascontiguousarray(S).transpose(0, 3, 2, 1)
     out["alpha"] = rng.uniform(0.5, 50.0, size=(N, T))
     return out
+
+
+def bsp_inputs(b, m, T, N, seed=SEED, coupling=1e-2):
+    """Inputs of the belief-space backward pass (bspilqr/src/util.cpp:83-91): the iLQR stack renamed
+    (Q, q, R, r, P <- Cxx, cx, Cuu, cu, Cxu; F, G <- A, B) plus p ~ N(0,1) (N, b^2, T+1) and the belief-covariance
+    couplings T, X (b^2, b), U, Y (b^2, b^2), V, Z (b^2, m) ~ coupling * N(0,1), all with T slices."""
+    base = backward_inputs(b, m, T, N, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(seed + 104729))
+    bb = b * b
+    out = dict(Q=base["Cxx"], q=base["cx"], R=base["Cuu"], r=base["cu"], P=base["Cxu"], F=base["A"], G=base["B"])
+    out["p"] = np.ascontiguousarray(rng.standard_normal((N, T + 1, bb))).transpose(0, 2, 1)
+    for k, cols in (("T", b), ("U", bb), ("V", m), ("X", b), ("Y", bb), ("Z", m)):
+        out[k] = np.ascontiguousarray(coupling * rng.standard_normal((N, T, cols, bb))).transpose(0, 3, 2, 1)
+    return out
