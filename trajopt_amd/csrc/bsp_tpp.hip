@@ -7,8 +7,6 @@
 // being held: this pass is bound by those bytes (8 (2b^4 + 2b^3 + 2b^2 m + ...) per step, 6.3 KB at b = 4, m = 2).
 // Reference quirks (oracle/bsp_oracle.hpp): dS starts at zero here; tau_mode picks what util.cpp:158's read of the
 // not-yet-assigned tau.col(i) means (0: tau.col(i+1), the evident intent; 1: zeros).
-#include <type_traits>
-
 #include "gps_common.h"
 
 namespace trajopt {
@@ -37,15 +35,43 @@ __global__ __launch_bounds__(64) void bsp_tpp_kernel(BspArgs a) {
     double dS0 = 0.0, dS1 = 0.0;
     int where = -1;
 
-    // out[j] += scale * sum_k Mat[k, j] * v[k] for a (BB x COLS) operand streamed from memory
-    auto acc_t = [&](auto& out, const double* arr, auto cols_tag, int t, const double (&v)[BB], double scale) {
-        constexpr int COLS = decltype(cols_tag)::value;
+    // b = 4: the covariance channel's operands are streamed, two columns (2 b^2 = 32 loads, issued back to back into
+    // registers) at a time, by RUN-TIME loops over the columns with walking pointers; the vectors they multiply
+    // (vec(S), tau) and the sums they produce sit in this lane's column of LDS, which takes a run-time index where a
+    // register array cannot.  Fully unrolled, the 800 loads of a step each carried a loop-invariant 64-bit offset that
+    // hipcc hoisted out of the time loop (830 spilled registers); one column per iteration with the loads feeding the
+    // multiply-adds directly ran the loads one after another (0.3 us each): both 26 ms where this form takes 1.9.
+    __shared__ double l_S[BB][64], l_tau[BB][64], l_e[BB][64], l_c[B][64], l_d[M][64];
+    const int ln = threadIdx.x;
+    // sum_k Mat[k, j] v[k] for columns j of a (BB x cols) operand at slice t -> out[j][ln] (+= when ACC)
+    auto stream = [&](const double* arr, int cols, int t, const double (*v)[64], double (*out)[64], double scale,
+                      bool acc) {
+        const double* col = arr + ((size_t)t * BB * cols) * NP + p;
+        // JW columns (JW b^2 loads) in flight at a time: a lone wave's loads each pay a full miss (the rows of a
+        // step lie NP * 8 bytes apart), so the count in flight is what sets the pace
+        constexpr int JW = 2;
+        int j = 0;
+#pragma unroll 1
+        for (; j + JW <= cols; j += JW, col += (size_t)JW * BB * NP) {
+            double x[JW][BB];
 #pragma unroll
-        for (int j = 0; j < COLS; ++j) {
+            for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+                for (int k = 0; k < BB; ++k) x[jj][k] = col[((size_t)jj * BB + k) * NP];
+#pragma unroll
+            for (int jj = 0; jj < JW; ++jj) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int k = 0; k < BB; ++k) sacc = fma(x[jj][k], v[k][ln], sacc);
+                out[j + jj][ln] = acc ? fma(scale, sacc, out[j + jj][ln]) : scale * sacc;
+            }
+        }
+#pragma unroll 1
+        for (; j < cols; ++j, col += (size_t)BB * NP) {
             double sacc = 0.0;
 #pragma unroll
-            for (int k = 0; k < BB; ++k) sacc = fma(arr[((size_t)t * (BB * COLS) + k + BB * j) * NP + p], v[k], sacc);
-            out[j] = fma(scale, sacc, out[j]);
+            for (int k = 0; k < BB; ++k) sacc = fma(col[(size_t)k * NP], v[k][ln], sacc);
+            out[j][ln] = acc ? fma(scale, sacc, out[j][ln]) : scale * sacc;
         }
     };
 
@@ -59,13 +85,48 @@ __global__ __launch_bounds__(64) void bsp_tpp_kernel(BspArgs a) {
         gld<B>(c, io.q, B, t, NP, p);
         gld<M>(d, io.r, M, t, NP, p);
         gld<BB>(e, io.p, BB, t, NP, p);
-        // the covariance channel (:152-158): streamed operands
-        acc_t(c, io.T, std::integral_constant<int, B>{}, t, tau, 1.0);
-        acc_t(c, io.X, std::integral_constant<int, B>{}, t, S, 0.5);   // vectorise(S): column-major = the array itself
-        acc_t(d, io.V, std::integral_constant<int, M>{}, t, tau, 1.0);
-        acc_t(d, io.Z, std::integral_constant<int, M>{}, t, S, 0.5);
-        if (a.tau_mode == 0) acc_t(e, io.U, std::integral_constant<int, BB>{}, t, tau, 1.0);
-        acc_t(e, io.Y, std::integral_constant<int, BB>{}, t, S, 0.5);
+        // the covariance channel (:152-158)
+        if constexpr (BB <= 4) {
+            // b = 2: the six operands are 64 doubles in all - load them in one go, multiply from registers
+            double mT[BB * B], mX[BB * B], mV[BB * M], mZ[BB * M], mU[BB * BB], mY[BB * BB];
+            gld<BB * B>(mT, io.T, BB * B, t, NP, p);
+            gld<BB * B>(mX, io.X, BB * B, t, NP, p);
+            gld<BB * M>(mV, io.V, BB * M, t, NP, p);
+            gld<BB * M>(mZ, io.Z, BB * M, t, NP, p);
+            gld<BB * BB>(mY, io.Y, BB * BB, t, NP, p);
+            if (a.tau_mode == 0) gld<BB * BB>(mU, io.U, BB * BB, t, NP, p);
+            auto dot = [&](const double* mat, int j, const double (&v)[BB]) {
+                double x = 0.0;
+#pragma unroll
+                for (int k = 0; k < BB; ++k) x = fma(mat[k + BB * j], v[k], x);
+                return x;
+            };
+#pragma unroll
+            for (int j = 0; j < B; ++j) c[j] = fma(0.5, dot(mX, j, S), c[j] + dot(mT, j, tau));
+#pragma unroll
+            for (int j = 0; j < M; ++j) d[j] = fma(0.5, dot(mZ, j, S), d[j] + dot(mV, j, tau));
+#pragma unroll
+            for (int j = 0; j < BB; ++j) {
+                if (a.tau_mode == 0) e[j] += dot(mU, j, tau);
+                e[j] = fma(0.5, dot(mY, j, S), e[j]);
+            }
+        } else {
+            // b = 4: streamed operands
+#pragma unroll
+            for (int k = 0; k < BB; ++k) { l_S[k][ln] = S[k]; l_tau[k][ln] = tau[k]; }   // vectorise(S) = the array itself
+            stream(io.T, B, t, l_tau, l_c, 1.0, false);
+            stream(io.X, B, t, l_S, l_c, 0.5, true);
+            stream(io.V, M, t, l_tau, l_d, 1.0, false);
+            stream(io.Z, M, t, l_S, l_d, 0.5, true);
+            stream(io.Y, BB, t, l_S, l_e, 0.5, false);
+            if (a.tau_mode == 0) stream(io.U, BB, t, l_tau, l_e, 1.0, true);
+#pragma unroll
+            for (int i = 0; i < B; ++i) c[i] += l_c[i][ln];
+#pragma unroll
+            for (int i = 0; i < M; ++i) d[i] += l_d[i][ln];
+#pragma unroll
+            for (int k = 0; k < BB; ++k) e[k] += l_e[k][ln];
+        }
         // W = S F, Z = S G
         double W[BB], Zg[B * M];
 #pragma unroll
