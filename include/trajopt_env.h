@@ -35,6 +35,7 @@ enum {
     TRAJOPT_ENV_LQR = 4,             /* envs/lqr/lqr_v0.py:8-114 (affine LTI)      dx<=12 du<=4 */
     TRAJOPT_ENV_QUADROTOR = 5,       /* build-defined (no counterpart in the reference) dx=12 du=4 */
     TRAJOPT_ENV_DOUBLE_PENDULUM = 6, /* envs/double_pendulum/double_pendulum.py:15-172    dx=4 du=2 */
+    TRAJOPT_ENV_QUAD_PENDULUM = 8,   /* envs/quad_pendulum/quad_pendulum.py:14-303 (four links)        dx=8 du=4 */
     TRAJOPT_ENV_ROBOT = 7            /* envs/robot/robot.py:8-102 (car-like robot; its RK4 steps by -dt, :62-67) dx=4 du=2 */
 };
 

@@ -160,6 +160,77 @@ template <class X> void f_quadrotor(const trajopt_env_t& e, const X* x, const X*
     dx[11] = (tz - (Iyy - Ixx) * p * q) / Izz;
 }
 
+template <class X> void f_quad_pendulum(const trajopt_env_t& e, const X* x, const X* u, X* dx) {
+    // quad_pendulum.py:62-228; the linear system M dd = r (the reference expands inv(M) r by cofactors, :188-222)
+    // is solved by Gaussian elimination with partial pivoting on the values
+    const double G = e.phys[0], m1 = e.phys[1], m2 = e.phys[2], m3 = e.phys[3], m4 = e.phys[4];
+    const double l1 = e.phys[5], l2 = e.phys[6], l3 = e.phys[7], l4 = e.phys[8];
+    const double fr1 = e.phys[9], fr2 = e.phys[10], fr3 = e.phys[11], fr4 = e.phys[12];
+    const double I1 = m1 * (l1 * l1 + 1e-4) / 3.0, I2 = m2 * (l2 * l2 + 1e-4) / 3.0, I3 = m3 * (l3 * l3 + 1e-4) / 3.0,
+                 I4 = m4 * (l4 * l4 + 1e-4) / 3.0;
+    const double h1 = 0.5 * l1, h2 = 0.5 * l2, h3 = 0.5 * l3, h4 = 0.5 * l4;   // centres of mass
+    // lumped constants: w4 = l4cm m4, w3 = l3cm m3 + l3 m4, w2 = l2cm m2 + l2 (m3 + m4), w1 = l1cm m1 + l1 (m2 + m3 + m4)
+    const double w4 = h4 * m4, w3 = h3 * m3 + l3 * m4, w2 = h2 * m2 + l2 * (m3 + m4), e8 = l1 * (m2 + m3 + m4);
+    const X w1 = x[4], wv2 = x[5], wv3 = x[6], wv4 = x[7];   // angular velocities
+    const X t1 = x[0] + M_PI;   // downward position = pi (quad_pendulum.py:77)
+    const X s1 = sin(t1), c1 = cos(t1), s2 = sin(x[1]), c2 = cos(x[1]), s3 = sin(x[2]), c3 = cos(x[2]),
+            s4 = sin(x[3]), c4 = cos(x[3]);
+    // sums of angles by the addition formulas, as the reference forms them (:92-103)
+    const X s12 = s1 * c2 + c1 * s2, c12 = c1 * c2 - s1 * s2, s23 = s2 * c3 + c2 * s3, c23 = c2 * c3 - s2 * s3;
+    const X s34 = s3 * c4 + c3 * s4, c34 = c3 * c4 - s3 * s4;
+    const X s1234 = s12 * c34 + c12 * s34, s123 = s12 * c3 + c12 * s3, s234 = s2 * c34 + c2 * s34, c234 = c2 * c34 - s2 * s34;
+    // inertia matrix (symmetric; the reference's a..p, :147-181)
+    const X M44 = I4 + h4 * w4;
+    const X M34 = M44 + (l3 * w4) * c4;
+    const X M24 = M34 + (l2 * w4) * c34;
+    const X M14 = M24 + (l1 * w4) * c234;
+    const X M33 = I3 + M34 + h3 * (h3 * m3) + l3 * (l3 * m4) + (l3 * w4) * c4;
+    const X M23 = M33 + (l2 * w3) * c3 + (l2 * w4) * c34;
+    const X M13 = M23 + (l1 * w3) * c23 + (l1 * w4) * c234;
+    const X M22 = M23 + I2 + h2 * (h2 * m2) + (l2 * l2) * (m3 + m4) + (l2 * w3) * c3 + (l2 * w4) * c34;
+    const X M12 = M22 + M13 - M23 + (l1 * w2) * c2;
+    const X M11 = 2.0 * M12 + I1 - M22 + (h1 * h1) * m1 + l1 * e8;
+    // velocity products and generalised forces (:105-145, :152-186)
+    const X v12 = w1 + wv2, v123 = v12 + wv3, q11 = w1 * w1, q12 = v12 * v12;
+    const X e4b = 2.0 * w1 * wv3 + 2.0 * wv2 * wv3 + wv3 * wv3;
+    const X e4a = 2.0 * w1 * wv4 + 2.0 * wv2 * wv4 + 2.0 * wv3 * wv4 + wv4 * wv4;
+    const X e9a = 2.0 * w1 * wv2 + wv2 * wv2, e9 = e9a + e4b;
+    const X e1 = G * (s123 * w3 + s1234 * w4);
+    const X e2 = (2.0 * v123 + wv4) * wv4 * (l3 * w4) * s4;
+    const X e3 = (G * w2) * s12;
+    const X e4 = (e4b + e4a) * ((l2 * w4) * s34);
+    const X e5a = q11 * l1 * s234, e5 = w4 * e5a;
+    const X e6 = e4b * (l2 * w3) * s3;
+    const X ls23 = (l1 * w3) * s23;
+    const X r4 = u[3] - fr4 * wv4 - w4 * (v123 * v123 * l3 * s4 + q12 * l2 * s34 + e5a + G * s1234);
+    const X r3 = u[2] - fr3 * wv3 - ((q12 * (l2 * w3) * s3 + q11 * ls23) - e2 + q12 * ((l2 * w4) * s34) + e5 + e1);
+    const X r2 = u[1] - fr2 * wv2 - (q11 * (l1 * w2) * s2 - e6 + q11 * ls23 - e2 - e4 + e5 + e3 + e1);
+    const X r1 = u[0] - fr1 * w1 - (-e9a * (l1 * w2) * s2 - e6 - e9 * ls23 - e2 - e4 - (e9 + e4a) * (l1 * w4) * s234 + e3 +
+                                    G * (h1 * m1 + e8) * s1 + e1);
+    X Mm[4][4] = {{M11, M12, M13, M14}, {M12, M22, M23, M24}, {M13, M23, M33, M34}, {M14, M24, M34, M44}};
+    X rhs[4] = {r1, r2, r3, r4};
+    int piv[4] = {0, 1, 2, 3};
+    for (int k = 0; k < 4; ++k) {
+        int p = k;
+        for (int i = k + 1; i < 4; ++i)
+            if (std::fabs(val(Mm[piv[i]][k])) > std::fabs(val(Mm[piv[p]][k]))) p = i;
+        int tmp = piv[k]; piv[k] = piv[p]; piv[p] = tmp;
+        for (int i = k + 1; i < 4; ++i) {
+            X fct = Mm[piv[i]][k] / Mm[piv[k]][k];
+            for (int j = k; j < 4; ++j) Mm[piv[i]][j] = Mm[piv[i]][j] - fct * Mm[piv[k]][j];
+            rhs[piv[i]] = rhs[piv[i]] - fct * rhs[piv[k]];
+        }
+    }
+    X dd[4];
+    for (int i = 3; i >= 0; --i) {
+        X sacc = rhs[piv[i]];
+        for (int j = i + 1; j < 4; ++j) sacc = sacc - Mm[piv[i]][j] * dd[j];
+        dd[i] = sacc / Mm[piv[i]][i];
+    }
+    dx[0] = w1; dx[1] = wv2; dx[2] = wv3; dx[3] = wv4;
+    dx[4] = dd[0]; dx[5] = dd[1]; dx[6] = dd[2]; dx[7] = dd[3];
+}
+
 template <class X> void f_robot(const trajopt_env_t& e, const X* x, const X* u, X* dx) {
     // robot.py:53-61
     const double l = e.phys[0];
@@ -177,6 +248,7 @@ template <class X> void vector_field(const trajopt_env_t& e, const X* x, const X
         case TRAJOPT_ENV_QUADROTOR: f_quadrotor(e, x, u, dx); break;
         case TRAJOPT_ENV_DOUBLE_PENDULUM: f_double_pendulum(e, x, u, dx); break;
         case TRAJOPT_ENV_ROBOT: f_robot(e, x, u, dx); break;
+        case TRAJOPT_ENV_QUAD_PENDULUM: f_quad_pendulum(e, x, u, dx); break;
         default: break;
     }
 }
@@ -314,6 +386,7 @@ inline int dynamics_jacobians(const trajopt_env_t& e, const double* x, const dou
     else if (n == 4 && m == 1) dynamics_jacobians_T<4, 1>(e, x, u, A, B, xn_out);
     else if (n == 6 && m == 1) dynamics_jacobians_T<6, 1>(e, x, u, A, B, xn_out);
     else if (n == 12 && m == 4) dynamics_jacobians_T<12, 4>(e, x, u, A, B, xn_out);
+    else if (n == 8 && m == 4) dynamics_jacobians_T<8, 4>(e, x, u, A, B, xn_out);
     else if (n == 2 && m == 2) dynamics_jacobians_T<2, 2>(e, x, u, A, B, xn_out);
     else if (n == 4 && m == 2) dynamics_jacobians_T<4, 2>(e, x, u, A, B, xn_out);
     else if (n == 3 && m == 1) dynamics_jacobians_T<3, 1>(e, x, u, A, B, xn_out);

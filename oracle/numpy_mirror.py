@@ -134,6 +134,38 @@ def _clip(x, lim):
     return r
 
 
+def _quad_pendulum_f(x, u):
+    """Four-link planar chain from first principles (an independent derivation, not the reference's expanded
+    expressions): link k has absolute angle phi_k = th_1 + pi + th_2 + ... + th_k, mass 1, length 1, centre of mass at
+    1/2, inertia m (l^2 + 1e-4) / 3 about the centre as quad_pendulum.py:74 defines it; joint friction 0.025.
+    T = 1/2 sum m |v_ck|^2 + 1/2 sum I_k dphi_k^2, V = g sum m y_ck (th_1 = 0 upright); Euler-Lagrange:
+    M ddq + (sum_i dq_i dM/dq_i) dq - 1/2 [dq' dM/dq_k dq]_k + dV/dq = u - friction dq.
+    Written with analytic derivatives only, so that it stays holomorphic for the complex-step Jacobians."""
+    g = 9.81
+    m, l, fr = np.ones(4), np.ones(4), 0.025 * np.ones(4)
+    I = m * (l ** 2 + 1e-4) / 3.0
+    x = np.asarray(x)
+    q, dq = x[:4], x[4:]
+    cum = np.tril(np.ones((4, 4)))                      # phi = cum @ th (+ pi)
+    phi = cum @ q + np.pi
+    sp, cp = np.sin(phi), np.cos(phi)
+    W = np.array([[l[j] if j < k else (0.5 * l[k] if j == k else 0.0) for j in range(4)] for k in range(4)])
+    # centre k: sum_j W[k, j] (sin phi_j, -cos phi_j); velocity Jacobians w.r.t. th
+    Jx = (W * cp[None, :]) @ cum
+    Jy = (W * sp[None, :]) @ cum
+    Mq = sum(m[k] * (np.outer(Jx[k], Jx[k]) + np.outer(Jy[k], Jy[k])) + I[k] * np.outer(cum[k], cum[k]) for k in range(4))
+    dM = []
+    for i in range(4):
+        dJx = (W * (-sp * cum[:, i])[None, :]) @ cum       # d phi_j / d th_i = cum[j, i]
+        dJy = (W * (cp * cum[:, i])[None, :]) @ cum
+        dM.append(sum(m[k] * (np.outer(dJx[k], Jx[k]) + np.outer(Jx[k], dJx[k]) + np.outer(dJy[k], Jy[k])
+                              + np.outer(Jy[k], dJy[k])) for k in range(4)))
+    dV = np.array([g * np.sum(m * (W @ (sp * cum[:, i]))) for i in range(4)])   # y_ck = -sum_j W[k, j] cos phi_j
+    cor = sum(dq[i] * dM[i] for i in range(4)) @ dq - 0.5 * np.array([dq @ dM[k] @ dq for k in range(4)])
+    dd = np.linalg.solve(Mq, np.asarray(u) - fr * dq - cor - dV)
+    return np.concatenate([dq, dd])
+
+
 class Env:
     """Parameter bag with the reference's constants; `name` selects the vector field."""
 
@@ -185,6 +217,11 @@ class Env:
             self.umax, self.xmax = np.full(self.m, inf), np.full(self.n, inf)
             self.cost_times_dt = True
             self.angles = []
+        elif name == "quad_pendulum":
+            self.n, self.m, self.dt = 8, 4, 0.01
+            self.umax, self.xmax = np.full(4, 25.), np.full(8, inf)
+            self.g, self.gw, self.uw = np.zeros(8), np.array([1e4] * 4 + [1e0] * 4), np.full(4, 1e-5)
+            self.angles = [0, 1, 2, 3]
         elif name == "robot":
             self.n, self.m, self.dt = 4, 2, 0.025
             self.umax, self.xmax = np.full(2, inf), np.full(4, inf)
@@ -287,6 +324,8 @@ class Env:
                              cph * cth * F / mass - g,
                              (tx - (Izz - Iyy) * q * r) / Ixx, (ty - (Ixx - Izz) * p * r) / Iyy,
                              (tz - (Iyy - Ixx) * p * q) / Izz])
+        if nm == "quad_pendulum":
+            return _quad_pendulum_f(x, u)
         if nm == "robot":
             return np.array([x[3] * np.cos(x[2]), x[3] * np.sin(x[2]), x[3] * np.tan(u[1]) / 0.1, u[0]])
         raise KeyError(nm)

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 MAX_STATE, MAX_ACT = 12, 4
-ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR, ENV_DOUBLE_PENDULUM, ENV_ROBOT = 1, 2, 3, 4, 5, 6, 7
+ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR, ENV_DOUBLE_PENDULUM, ENV_ROBOT, ENV_QUAD_PENDULUM = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 class EnvStruct(C.Structure):
@@ -128,6 +128,13 @@ def make_env(name, dt=None, uw=None, slew_rate=False, periodic=False, cartesian=
         fill(e.gw, [1e4, 1e4, 1e0, 1e0]); fill(e.uw, [1e-5] * 2 if uw is None else uw)
         fill(e.phys, [9.81, 1., 1., 1., 1., 0.025, 0.025])
         e.periodic = 0b0001 if periodic else 0
+    elif name == "quad_pendulum":  # envs/quad_pendulum/quad_pendulum.py:16-47,68-72
+        e.model, e.dm_state, e.dm_act = ENV_QUAD_PENDULUM, 8, 4
+        e.dt = 0.01 if dt is None else dt
+        fill(e.umax, [25.] * 4); fill(e.xmax, [inf] * 8); fill(e.goal, [0.] * 8)
+        fill(e.gw, [1e4] * 4 + [1e0] * 4); fill(e.uw, [1e-5] * 4 if uw is None else uw)
+        fill(e.phys, [9.81] + [1.] * 4 + [1.] * 4 + [0.025] * 4)
+        e.periodic = 0b00001111 if periodic else 0
     elif name == "robot":  # envs/robot/robot.py:10-36
         e.model, e.dm_state, e.dm_act = ENV_ROBOT, 4, 2
         e.dt = 0.025 if dt is None else dt

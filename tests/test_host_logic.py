@@ -50,7 +50,7 @@ def test_env_registry_and_struct():
     from trajopt_amd import envs
     for name, ref_id in (("pendulum", "Pendulum-TO-v0"), ("cartpole", "Cartpole-TO-v0"),
                          ("double_cartpole", "DoubleCartpole-TO-v0"), ("lqr", "LQR-TO-v0"),
-                         ("double_pendulum", "DoublePendulum-TO-v0"), ("robot", "Robot-TO-v0"),
+                         ("double_pendulum", "DoublePendulum-TO-v0"), ("robot", "Robot-TO-v0"), ("quad_pendulum", "QuadPendulum-TO-v0"),
                          ("lqr_v1", "LQR-TO-v1"), ("lqr_v2", "LQR-TO-v2")):
         e = envs.make(ref_id)
         assert type(e) is type(envs.make(name))

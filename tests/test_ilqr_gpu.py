@@ -9,7 +9,7 @@ from tests.util import TOL, assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
-ENVS = ["pendulum", "cartpole", "double_cartpole", "quadrotor", "lqr", "double_pendulum", "robot", "lqr_v1", "lqr_v2",
+ENVS = ["pendulum", "cartpole", "double_cartpole", "quadrotor", "lqr", "double_pendulum", "robot", "lqr_v1", "lqr_v2", "quad_pendulum",
         # the ...WithCartesianCost classes: nonlinear cost features, frozen-Jacobian derivatives
         "pendulum_cartesian", "cartpole_cartesian", "double_cartpole_cartesian", "double_pendulum_cartesian"]
 
@@ -34,7 +34,7 @@ def _pair(name, **kw):
 
 def _rand_state(name, rng, N):
     n = {"pendulum": 2, "cartpole": 4, "double_cartpole": 6, "quadrotor": 12, "lqr": 2, "double_pendulum": 4, "robot": 4,
-         "lqr_v1": 2, "lqr_v2": 2}[_base(name)]
+         "lqr_v1": 2, "lqr_v2": 2, "quad_pendulum": 8}[_base(name)]
     x = rng.standard_normal((N, n))
     if name == "quadrotor":
         x[:, 3:6] *= 0.3  # keep away from the Euler singularity
@@ -43,7 +43,7 @@ def _rand_state(name, rng, N):
 
 def test_env_struct_matches_oracle_struct():
     for name in ENVS:
-        for kw in ({}, dict(dt=0.05, uw=[1e-2] * {"quadrotor": 4, "double_pendulum": 2, "robot": 2}.get(_base(name), 1), slew_rate=True, periodic=True)):
+        for kw in ({}, dict(dt=0.05, uw=[1e-2] * {"quadrotor": 4, "double_pendulum": 2, "robot": 2, "quad_pendulum": 4}.get(_base(name), 1), slew_rate=True, periodic=True)):
             pe, oe = _pair(name, **kw)
             assert bytes(pe.struct()) == bytes(oe), name
 
@@ -53,7 +53,7 @@ def test_env_struct_matches_oracle_struct():
 def test_env_step_matches_oracle(oracle, name, layout):
     import torch
     from trajopt_amd import _lib, layout as L
-    pe, oe = _pair(name, slew_rate=True, periodic=(_base(name) in ("pendulum", "cartpole", "double_cartpole", "double_pendulum")))
+    pe, oe = _pair(name, slew_rate=True, periodic=(_base(name) in ("pendulum", "cartpole", "double_cartpole", "double_pendulum", "quad_pendulum")))
     rng = np.random.default_rng(3)
     N = 130
     n, m = pe.dm_state, pe.dm_act
@@ -198,6 +198,7 @@ def _solve_pair(oracle, name, N, T, iters, seed=1337, scale=1e-2, gains_layout=N
     ("lqr", 60, 5, dict()),
     ("double_pendulum", 50, 4, dict(dt=0.02)),                # a further env model, dx = 4, du = 2
     ("robot", 50, 4, dict()),                                 # 8f.3: dx = 4, du = 2, RK4 by -dt, cost x dt
+    ("quad_pendulum", 30, 2, dict(dt=0.01)),                  # 8f.3: dx = 8, du = 4 (matrix-core backward kernel); chaotic: a 3rd iteration amplifies round-off into a different accept decision
     ("lqr_v1", 60, 4, dict()),
     ("lqr_v2", 60, 4, dict()),
     ("cartpole_cartesian", 60, 4, dict(dt=0.02, uw=[1e-5])),  # 8f.3: Cartesian cost - dense Cxx, no structured cost

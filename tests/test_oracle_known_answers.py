@@ -178,7 +178,8 @@ def test_is_sympd_rule(oracle, mirror):
 
 
 ENVS = [("pendulum", dict(dt=0.05)), ("cartpole", dict(dt=0.02)), ("double_cartpole", dict()), ("quadrotor", dict()),
-        ("lqr", dict()), ("double_pendulum", dict(dt=0.02)), ("robot", dict()), ("lqr_v1", dict()), ("lqr_v2", dict())]
+        ("lqr", dict()), ("double_pendulum", dict(dt=0.02)), ("robot", dict()), ("lqr_v1", dict()), ("lqr_v2", dict()),
+        ("quad_pendulum", dict())]   # its mirror is an independent Lagrangian derivation of the four-link chain
 
 
 @pytest.mark.parametrize("name,kw", ENVS)
@@ -190,7 +191,7 @@ def test_env_models_and_derivatives_vs_mirror(oracle, mirror, name, kw):
         x = rng.standard_normal(me.n)
         if name == "quadrotor":
             x[3:6] *= 0.3
-        u = 3.0 * rng.standard_normal(me.m) if trial % 3 else 20.0 * np.ones(me.m)  # saturated every 3rd
+        u = 3.0 * rng.standard_normal(me.m) if trial % 3 else 30.0 * np.ones(me.m)  # saturated every 3rd
         if name == "robot":
             u[1] = 0.4 * np.tanh(u[1])   # steering angle away from tan's poles
         ul = rng.standard_normal(me.m)

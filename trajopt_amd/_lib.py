@@ -16,7 +16,7 @@ MAX_ALPHAS = 16
 ABI_VERSION = 3          # include/trajopt_amd.h::TRAJOPT_ABI_VERSION
 MAX_STATE, MAX_ACT = 12, 4
 
-ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR, ENV_DOUBLE_PENDULUM, ENV_ROBOT = 1, 2, 3, 4, 5, 6, 7
+ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR, ENV_DOUBLE_PENDULUM, ENV_ROBOT, ENV_QUAD_PENDULUM = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 class TrajoptError(RuntimeError):

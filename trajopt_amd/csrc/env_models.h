@@ -245,6 +245,81 @@ template <> struct Model<TRAJOPT_ENV_DOUBLE_PENDULUM> {
     }
 };
 
+template <> struct Model<TRAJOPT_ENV_QUAD_PENDULUM> {
+    static constexpr int N = 8, M = 4;
+    // quad_pendulum.py:62-228: four torque-driven links (the PolicySearchToolbox / Atkeson model).  The reference
+    // inverts the 4 x 4 inertia matrix by cofactors (:188-222); here M dd = r is solved by symmetric elimination
+    // (M is a mass matrix: positive definite), which is the same solution at a third of the arithmetic.
+    // phys = {G, m1..m4, l1..l4, friction1..4}
+    template <class X> static __device__ __forceinline__ void f(const trajopt_env_t& e, const X (&x)[N], const X (&u)[M], X (&dx)[N]) {
+        const double G = e.phys[0], m1 = e.phys[1], m2 = e.phys[2], m3 = e.phys[3], m4 = e.phys[4];
+        const double l1 = e.phys[5], l2 = e.phys[6], l3 = e.phys[7], l4 = e.phys[8];
+        const double fr1 = e.phys[9], fr2 = e.phys[10], fr3 = e.phys[11], fr4 = e.phys[12];
+        const double I1 = m1 * (l1 * l1 + 1e-4) / 3.0, I2 = m2 * (l2 * l2 + 1e-4) / 3.0, I3 = m3 * (l3 * l3 + 1e-4) / 3.0,
+                     I4 = m4 * (l4 * l4 + 1e-4) / 3.0;
+        const double h1 = 0.5 * l1, h2 = 0.5 * l2, h3 = 0.5 * l3, h4 = 0.5 * l4;   // centres of mass
+        // lumped constants: w4 = l4cm m4, w3 = l3cm m3 + l3 m4, w2 = l2cm m2 + l2 (m3 + m4), w1 = l1cm m1 + l1 (m2 + m3 + m4)
+        const double w4 = h4 * m4, w3 = h3 * m3 + l3 * m4, w2 = h2 * m2 + l2 * (m3 + m4), e8 = l1 * (m2 + m3 + m4);
+        const X w1 = x[4], wv2 = x[5], wv3 = x[6], wv4 = x[7];   // angular velocities
+        X s1, c1, s2, c2, s3, c3, s4, c4;
+        sincos_g(x[0] + M_PI, s1, c1);   // downward position = pi (quad_pendulum.py:77)
+        sincos_g(x[1], s2, c2);
+        sincos_g(x[2], s3, c3);
+        sincos_g(x[3], s4, c4);
+        // sums of angles by the addition formulas, as the reference forms them (:92-103)
+        const X s12 = s1 * c2 + c1 * s2, c12 = c1 * c2 - s1 * s2, s23 = s2 * c3 + c2 * s3, c23 = c2 * c3 - s2 * s3;
+        const X s34 = s3 * c4 + c3 * s4, c34 = c3 * c4 - s3 * s4;
+        const X s1234 = s12 * c34 + c12 * s34, s123 = s12 * c3 + c12 * s3, s234 = s2 * c34 + c2 * s34, c234 = c2 * c34 - s2 * s34;
+        // inertia matrix (symmetric; the reference's a..p, :147-181)
+        const double M44 = I4 + h4 * w4;
+        const X M34 = M44 + (l3 * w4) * c4;
+        const X M24 = M34 + (l2 * w4) * c34;
+        const X M14 = M24 + (l1 * w4) * c234;
+        const X M33 = I3 + M34 + h3 * (h3 * m3) + l3 * (l3 * m4) + (l3 * w4) * c4;
+        const X M23 = M33 + (l2 * w3) * c3 + (l2 * w4) * c34;
+        const X M13 = M23 + (l1 * w3) * c23 + (l1 * w4) * c234;
+        const X M22 = M23 + I2 + h2 * (h2 * m2) + (l2 * l2) * (m3 + m4) + (l2 * w3) * c3 + (l2 * w4) * c34;
+        const X M12 = M22 + M13 - M23 + (l1 * w2) * c2;
+        const X M11 = 2.0 * M12 + I1 - M22 + (h1 * h1) * m1 + l1 * e8;
+        // velocity products and generalised forces (:105-145, :152-186)
+        const X v12 = w1 + wv2, v123 = v12 + wv3, q11 = w1 * w1, q12 = v12 * v12;
+        const X e4b = 2.0 * w1 * wv3 + 2.0 * wv2 * wv3 + wv3 * wv3;
+        const X e4a = 2.0 * w1 * wv4 + 2.0 * wv2 * wv4 + 2.0 * wv3 * wv4 + wv4 * wv4;
+        const X e9a = 2.0 * w1 * wv2 + wv2 * wv2, e9 = e9a + e4b;
+        const X e1 = G * (s123 * w3 + s1234 * w4);
+        const X e2 = (2.0 * v123 + wv4) * wv4 * (l3 * w4) * s4;
+        const X e3 = (G * w2) * s12;
+        const X e4 = (e4b + e4a) * ((l2 * w4) * s34);
+        const X e5a = q11 * l1 * s234, e5 = w4 * e5a;
+        const X e6 = e4b * (l2 * w3) * s3;
+        const X ls23 = (l1 * w3) * s23;
+        const X r4 = u[3] - fr4 * wv4 - w4 * (v123 * v123 * l3 * s4 + q12 * l2 * s34 + e5a + G * s1234);
+        const X r3 = u[2] - fr3 * wv3 - ((q12 * (l2 * w3) * s3 + q11 * ls23) - e2 + q12 * ((l2 * w4) * s34) + e5 + e1);
+        const X r2 = u[1] - fr2 * wv2 - (q11 * (l1 * w2) * s2 - e6 + q11 * ls23 - e2 - e4 + e5 + e3 + e1);
+        const X r1 = u[0] - fr1 * w1 - (-e9a * (l1 * w2) * s2 - e6 - e9 * ls23 - e2 - e4 - (e9 + e4a) * (l1 * w4) * s234 + e3 +
+                                        G * (h1 * m1 + e8) * s1 + e1);
+        // L D L' elimination of [[M11 M12 M13 M14], [., M22 M23 M24], [., ., M33 M34], [., ., ., M44]]
+        const X i1 = recip_pos(M11);
+        const X a21 = M12 * i1, a31 = M13 * i1, a41 = M14 * i1;
+        const X B22 = M22 - a21 * M12, B23 = M23 - a21 * M13, B24 = M24 - a21 * M14;
+        const X B33 = M33 - a31 * M13, B34 = M34 - a31 * M14, B44 = M44 - a41 * M14;
+        const X y2 = r2 - a21 * r1, y3 = r3 - a31 * r1, y4 = r4 - a41 * r1;
+        const X i2 = recip_pos(B22);
+        const X a32 = B23 * i2, a42 = B24 * i2;
+        const X C33 = B33 - a32 * B23, C34 = B34 - a32 * B24, C44 = B44 - a42 * B24;
+        const X z3 = y3 - a32 * y2, z4 = y4 - a42 * y2;
+        const X i3 = recip_pos(C33);
+        const X a43 = C34 * i3;
+        const X D44 = C44 - a43 * C34;
+        const X d4 = (z4 - a43 * z3) * recip_pos(D44);
+        const X d3 = (z3 - C34 * d4) * i3;
+        const X d2 = (y2 - B23 * d3 - B24 * d4) * i2;
+        const X d1 = (r1 - M12 * d2 - M13 * d3 - M14 * d4) * i1;
+        dx[0] = w1; dx[1] = wv2; dx[2] = wv3; dx[3] = wv4;
+        dx[4] = d1; dx[5] = d2; dx[6] = d3; dx[7] = d4;
+    }
+};
+
 template <> struct Model<TRAJOPT_ENV_ROBOT> {
     static constexpr int N = 4, M = 2;
     template <class X> static __device__ __forceinline__ void f(const trajopt_env_t& e, const X (&x)[N], const X (&u)[M], X (&dx)[N]) {

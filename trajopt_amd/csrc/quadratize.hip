@@ -253,6 +253,7 @@ template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_DOUBLE_CARTPOLE>> { static conste
 template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_QUADROTOR>> { static constexpr int KC = 4; };
 template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_DOUBLE_PENDULUM>> { static constexpr int KC = 3; };
 template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_ROBOT>> { static constexpr int KC = 3; };
+template <> struct ChunkOf<SysPhys<TRAJOPT_ENV_QUAD_PENDULUM>> { static constexpr int KC = 4; };
 
 // the Riccati fix-up kernel reads A, B, C.. with the input layout flag: mixed layouts are an iLQR-driver feature
 static inline bool a_convention_needs_same_layout(int convention, int layout, int out_layout) {

@@ -98,6 +98,9 @@ inline bool dispatch_model(const trajopt_env_t& e, F&& fn) {
         case TRAJOPT_ENV_DOUBLE_PENDULUM:
             if (e.dm_state != 4 || e.dm_act != 2) return false;
             fn.template operator()<SysPhys<TRAJOPT_ENV_DOUBLE_PENDULUM>>(); return true;
+        case TRAJOPT_ENV_QUAD_PENDULUM:
+            if (e.dm_state != 8 || e.dm_act != 4) return false;
+            fn.template operator()<SysPhys<TRAJOPT_ENV_QUAD_PENDULUM>>(); return true;
         case TRAJOPT_ENV_ROBOT:
             if (e.dm_state != 4 || e.dm_act != 2) return false;
             fn.template operator()<SysPhys<TRAJOPT_ENV_ROBOT>>(); return true;

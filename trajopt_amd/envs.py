@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_DOUBLE_PENDULUM, ENV_LQR, ENV_PENDULUM, ENV_QUADROTOR, ENV_ROBOT, MAX_ACT, MAX_STATE,
+from ._lib import (ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_DOUBLE_PENDULUM, ENV_LQR, ENV_PENDULUM, ENV_QUAD_PENDULUM, ENV_QUADROTOR, ENV_ROBOT, MAX_ACT, MAX_STATE,
                    EnvStruct)
 
 
@@ -220,6 +220,21 @@ class DoublePendulum(Env):
         super().__init__()
 
 
+class QuadPendulum(Env):
+    """/root/reference/trajopt/envs/quad_pendulum/quad_pendulum.py:14-303: four torque-driven links, dx = 8, du = 4."""
+    model, angles = ENV_QUAD_PENDULUM, (0, 1, 2, 3)
+    phys = (9.81,) + (1.,) * 4 + (1.,) * 4 + (0.025,) * 4   # G, masses, lengths, friction (quad_pendulum.py:68-72)
+
+    def __init__(self):
+        self.dm_state, self.dm_act, self.dt = 8, 4, 0.01
+        self.sigma = 1e-8 * np.eye(8)
+        self.g, self.gw = np.zeros(8), np.array([1e4] * 4 + [1e0] * 4)
+        self.xmax = np.full(8, np.inf)
+        self.uw, self.umax = 1e-5 * np.ones(4), 25. * np.ones(4)
+        self.x0, self.sigma0 = np.array([np.pi] + [0.] * 7), 1e-4 * np.eye(8)
+        super().__init__()
+
+
 class PendulumWithCartesianCost(Pendulum):
     """/root/reference/trajopt/envs/pendulum/pendulum.py:152-162: cost on [cos th, sin th, dth]."""
     features = ((1, 0), (2, 0), (0, 1))
@@ -349,6 +364,7 @@ _REGISTRY = {
     "pendulum_cartesian": PendulumWithCartesianCost, "cartpole_cartesian": CartpoleWithCartesianCost,
     "double_cartpole_cartesian": DoubleCartpoleWithCartesianCost,
     "double_pendulum_cartesian": DoublePendulumWithCartesianCost,
+    "QuadPendulum-TO-v0": QuadPendulum, "quad_pendulum": QuadPendulum,
     "LQR-TO-v1": LQRv1, "LQR-TO-v2": LQRv2, "Robot-TO-v0": Robot, "lqr_v1": LQRv1, "lqr_v2": LQRv2, "robot": Robot,
     "pendulum": Pendulum, "cartpole": Cartpole, "double_cartpole": DoubleCartpole, "lqr": LQRv0,
     "quadrotor": Quadrotor, "Quadrotor-TO-v0": Quadrotor,
