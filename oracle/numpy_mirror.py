@@ -245,6 +245,9 @@ class Env:
                                                        x[2], x[3], x[4]]),   # double_cartpole.py:226-230, as written
                 "double_pendulum": lambda x: np.array([np.cos(x[0]), np.sin(x[0]), np.cos(x[1]), np.sin(x[1]),
                                                        x[2], x[3]]),
+                "quad_pendulum": lambda x: np.array([np.cos(x[0]), np.sin(x[0]), np.cos(x[1]), np.sin(x[1]),
+                                                     np.cos(x[2]), np.sin(x[2]), np.cos(x[3]), np.sin(x[3]),
+                                                     x[4], x[5], x[6], x[7]]),
             }[name]
             self.g, self.gw = {
                 "pendulum": (np.array([1., 0., 0.]), np.array([1e4, 1e4, 1e0])),
@@ -252,6 +255,7 @@ class Env:
                 "double_cartpole": (np.array([0., 1., 0., 1., 0., 0., 0., 0.]),
                                     np.array([1e1, 1e4, 1e4, 1e4, 1e4, 1e0, 1e0, 1e0])),
                 "double_pendulum": (np.array([1., 0., 1., 0., 0., 0.]), np.array([1e4, 1e4, 1e4, 1e4, 1e0, 1e0])),
+                "quad_pendulum": (np.array([1., 0.] * 4 + [0.] * 4), np.array([1e4] * 8 + [1e0] * 4)),
             }[name]
         if dt is not None:
             self.dt = dt

@@ -77,6 +77,8 @@ CARTESIAN = {
                         [0., 1., 0., 1., 0., 0., 0., 0.], [1e1, 1e4, 1e4, 1e4, 1e4, 1e0, 1e0, 1e0]),
     "double_pendulum": ([(1, 0), (2, 0), (1, 1), (2, 1), (0, 2), (0, 3)], [1., 0., 1., 0., 0., 0.],
                         [1e4, 1e4, 1e4, 1e4, 1e0, 1e0]),
+    "quad_pendulum": ([(1, 0), (2, 0), (1, 1), (2, 1), (1, 2), (2, 2), (1, 3), (2, 3), (0, 4), (0, 5), (0, 6), (0, 7)],
+                      [1., 0.] * 4 + [0.] * 4, [1e4] * 8 + [1e0] * 4),      # quad_pendulum.py:281-303
 }
 
 

@@ -57,7 +57,8 @@ def test_env_registry_and_struct():
         assert e.unwrapped is e and e.action_space.shape == (e.dm_act,) and e.observation_space.shape == (e.dm_state,)
         assert bytes(e.struct()) == bytes(O.make_env(name))
     for name, ref_id in (("pendulum", "Pendulum-TO-v1"), ("cartpole", "Cartpole-TO-v1"),
-                         ("double_cartpole", "DoubleCartpole-TO-v1"), ("double_pendulum", "DoublePendulum-TO-v1")):
+                         ("double_cartpole", "DoubleCartpole-TO-v1"), ("double_pendulum", "DoublePendulum-TO-v1"),
+                         ("quad_pendulum", "QuadPendulum-TO-v1")):
         e = envs.make(ref_id)                  # the ...WithCartesianCost classes
         assert type(e) is type(envs.make(name, cartesian=True)) and e.features is not None
         assert bytes(e.struct()) == bytes(O.make_env(name, cartesian=True))

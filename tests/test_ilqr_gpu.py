@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 ENVS = ["pendulum", "cartpole", "double_cartpole", "quadrotor", "lqr", "double_pendulum", "robot", "lqr_v1", "lqr_v2", "quad_pendulum",
         # the ...WithCartesianCost classes: nonlinear cost features, frozen-Jacobian derivatives
-        "pendulum_cartesian", "cartpole_cartesian", "double_cartpole_cartesian", "double_pendulum_cartesian"]
+        "pendulum_cartesian", "cartpole_cartesian", "double_cartpole_cartesian", "double_pendulum_cartesian",
+        "quad_pendulum_cartesian"]
 
 
 def _base(name):

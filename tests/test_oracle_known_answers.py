@@ -371,7 +371,7 @@ def test_gps_closed_forms(oracle, mirror):
         oracle.gps_kl_divergence(K, kff, sg, K, kff, bad, fw[0], fw[1], n, m, T)
 
 
-@pytest.mark.parametrize("name", ["pendulum", "cartpole", "double_cartpole", "double_pendulum"])
+@pytest.mark.parametrize("name", ["pendulum", "cartpole", "double_cartpole", "double_pendulum", "quad_pendulum"])
 def test_cartesian_cost_and_frozen_jacobian_derivatives(oracle, mirror, name):
     """The ...WithCartesianCost classes (e.g. cartpole.py:112-127,150-166): the cost is evaluated on z = J(y) y + j
     = phi(y) and differentiated with J, j held constant (getval) - the mirror builds exactly that quadratic with a

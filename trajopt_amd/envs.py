@@ -235,6 +235,16 @@ class QuadPendulum(Env):
         super().__init__()
 
 
+class QuadPendulumWithCartesianCost(QuadPendulum):
+    """/root/reference/trajopt/envs/quad_pendulum/quad_pendulum.py:281-303: cost on [cos, sin of the four angles, velocities]
+    (12 features: exactly the capacity of trajopt_env_t::goal / gw)."""
+    features = ((1, 0), (2, 0), (1, 1), (2, 1), (1, 2), (2, 2), (1, 3), (2, 3), (0, 4), (0, 5), (0, 6), (0, 7))
+
+    def __init__(self):
+        super().__init__()
+        self.g, self.gw = np.array([1., 0.] * 4 + [0.] * 4), np.array([1e4] * 8 + [1e0] * 4)
+
+
 class PendulumWithCartesianCost(Pendulum):
     """/root/reference/trajopt/envs/pendulum/pendulum.py:152-162: cost on [cos th, sin th, dth]."""
     features = ((1, 0), (2, 0), (0, 1))
@@ -361,6 +371,7 @@ _REGISTRY = {
     "LQR-TO-v0": LQRv0, "DoublePendulum-TO-v0": DoublePendulum, "double_pendulum": DoublePendulum,
     "Pendulum-TO-v1": PendulumWithCartesianCost, "Cartpole-TO-v1": CartpoleWithCartesianCost,
     "DoubleCartpole-TO-v1": DoubleCartpoleWithCartesianCost, "DoublePendulum-TO-v1": DoublePendulumWithCartesianCost,
+    "QuadPendulum-TO-v1": QuadPendulumWithCartesianCost, "quad_pendulum_cartesian": QuadPendulumWithCartesianCost,
     "pendulum_cartesian": PendulumWithCartesianCost, "cartpole_cartesian": CartpoleWithCartesianCost,
     "double_cartpole_cartesian": DoubleCartpoleWithCartesianCost,
     "double_pendulum_cartesian": DoublePendulumWithCartesianCost,
