@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/README or DESIGN.md section 4): CPU restatement of the remaining functions of
+// TEST INFRASTRUCTURE ONLY (never used by the product path): CPU restatement of the remaining functions of
 // the reference's GPS native module, /root/reference/trajopt/gps/src/util.cpp:83-269:
 //   kl_divergence :83-121, quad_expectation :123-134, augment_cost :136-193, forward_pass :195-269.
 // Parity unpinned: the reference holds no vectors for them and cannot be built here (Armadillo absent); pinned by
