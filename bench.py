@@ -72,9 +72,25 @@ def cpu_baseline(env_name, dt, uw, T, seed, budget_s=12.0):
         elapsed += sec
         done_steps += it * T
         problems += chunk
-    return {"value": done_steps / elapsed, "unit": "problem-timesteps/s", "cores": cores, "kind": "port",
-            "sample": "%d cartpole problems x T=%d x %d iLQR iterations (sequential first-accept line search), "
-                      "%.1f s on %d threads, oracle/liboracle.so -O3" % (problems, T, iters, elapsed, cores)}
+    out = {"value": done_steps / elapsed, "unit": "problem-timesteps/s", "cores": cores, "kind": "port",
+           "sample": "%d cartpole problems x T=%d x %d iLQR iterations (sequential first-accept line search), "
+                     "%.1f s on %d threads, oracle/liboracle.so -O3" % (problems, T, iters, elapsed, cores)}
+    # the same port on ONE core, and the NumPy mirror as an indication of the Python-level cost the
+    # reference pays per problem (its own autograd path is not runnable here and was not measured)
+    x0, kff0 = make_problem_set(pe, 64, T, seed + 104729)
+    sec, _, it = O.bench_ilqr(oe, T, x0, kff0.reshape(64, -1), iters, 1, opts=opts)
+    out["one_core"] = {"value": it * T / sec, "sample": "64 problems x %d iterations, %.1f s" % (iters, sec)}
+    try:
+        from oracle import numpy_mirror as Mi
+        me = Mi.Env(env_name, dt=dt, uw=[uw])
+        Tm = min(T, 50)
+        t0 = time.perf_counter()
+        Mi.ilqr_run(me, Tm, x0[0], kff0[0][:, :Tm], np.ones(Tm + 1), O.DEFAULT_ALPHAS, 1)
+        secm = time.perf_counter() - t0
+        out["numpy_mirror"] = {"value": Tm / secm, "sample": "1 problem x T=%d x 1 iteration, %.1f s, 1 core" % (Tm, secm)}
+    except Exception as exc:   # the mirror is an extra, never a reason to lose the bench line
+        out["numpy_mirror"] = {"value": None, "sample": "failed: %r" % (exc,)}
+    return out
 
 
 def main():
