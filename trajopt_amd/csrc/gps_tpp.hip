@@ -23,9 +23,10 @@ struct GpsArgs {
 template <int N, int M>
 struct GpsIn {
     double A[N * N], B[N * M], c[N], Cuu[M * M], Cxu[N * M], cx[N], cu[M], c0, alpha;
+    double S[N <= 4 ? N * N : 1], Cxx[N <= 4 ? N * N : 1];   // prefetched with the rest up to dx = 4 (see below)
 };
-// sigma_dyn[t] and Cxx[t] are not part of the prefetched set: the step loads them at its top and first uses them
-// after the V'F products, which keeps two sets + V + the step temporaries inside 512 VGPRs at dx = 6.
+// At dx = 6 sigma_dyn[t] and Cxx[t] are not part of the prefetched set: the step loads them at its top and first uses
+// them after the V'F products, which keeps two sets + V + the step temporaries inside 512 VGPRs.
 
 template <int N, int M>
 __device__ __forceinline__ void gps_load(GpsIn<N, M>& s, const trajopt_gps_backward_io_t& io, int t, size_t NP, size_t p) {
@@ -38,6 +39,10 @@ __device__ __forceinline__ void gps_load(GpsIn<N, M>& s, const trajopt_gps_backw
     gld<M>(s.cu, io.cu, M, t, NP, p);
     s.c0 = io.c0[(size_t)t * NP + p];
     s.alpha = io.alpha[(size_t)t * NP + p];
+    if constexpr (N <= 4) {
+        gld<N * N>(s.S, io.sigma_dyn, N * N, t, NP, p);
+        gld<N * N>(s.Cxx, io.Cxx, N * N, t, NP, p);
+    }
 }
 
 template <int N, int M, bool FULL>
@@ -58,8 +63,13 @@ __global__ __launch_bounds__(64) void gps_tpp_kernel(GpsArgs a) {
     auto step = [&](const GpsIn<N, M>& in, int t) -> bool {
         const double na = -1.0 / in.alpha;
         double W[N * N], Z[N * M], Vc[N], Sg[N * N], Cx[N * N];
-        gld<N * N>(Sg, io.sigma_dyn, N * N, t, NP, p);
-        gld<N * N>(Cx, io.Cxx, N * N, t, NP, p);
+        if constexpr (N <= 4) {
+#pragma unroll
+            for (int k = 0; k < N * N; ++k) { Sg[k] = in.S[k]; Cx[k] = in.Cxx[k]; }
+        } else {
+            gld<N * N>(Sg, io.sigma_dyn, N * N, t, NP, p);
+            gld<N * N>(Cx, io.Cxx, N * N, t, NP, p);
+        }
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
