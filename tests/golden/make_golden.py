@@ -1,8 +1,8 @@
 """Generates the golden fixtures in this directory.  PARITY UNPINNED: the reference ships no tests or
 fixtures and neither its native core (Armadillo + OpenBLAS) nor its Python (autograd, gym) can run in the
 build image, so these vectors come from the CPU oracle (oracle/liboracle.so, a restatement of
-/root/reference/trajopt/ilqr/src/util.cpp:83-182, riccati/riccati.py:100-126, ilqr/ilqr.py:89-237 and the env
-files), and are only written after two independent implementations agree on them:
+/root/reference/trajopt/ilqr/src/util.cpp:83-182, riccati/riccati.py:100-126, ilqr/ilqr.py:89-237, gps/src/util.cpp:83-374, bspilqr/src/util.cpp:83-204
+and the env files), and are only written after two independent implementations agree on them:
   * the NumPy mirror (oracle/numpy_mirror.py; complex-step Jacobians, np.linalg.inv) within 1e-10, and
   * the x87 long-double build of the same recursion within 1e-11.
 Run from the repo root:  python tests/golden/make_golden.py
@@ -84,6 +84,68 @@ def ilqr_case(name, env_name, T, iters, seed, **kw):
     np.savez(os.path.join(HERE, name + ".npz"), **d)
 
 
+GPS_ARGS = ("Cxx", "cx", "Cuu", "cu", "Cxu", "c0", "A", "B", "c", "sigma_dyn", "alpha")
+
+
+def gps_case(name, n, m, T, seed):
+    """One MBGPS dual evaluation (gps/mbgps.py:173-195): augment_cost -> backward_pass -> forward_pass ->
+    quad_expectation -> kl_divergence (gps/src/util.cpp:83-374), every stage cross-checked before it is written."""
+    q = S.problem(S.gps_inputs(n, m, T, 1, seed=seed), 0)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    # the "last" controller: the oracle's own solution of the plain problem, perturbed
+    o0, f0 = O.gps_backward_pass(*[q[k] for k in GPS_ARGS], n, m, T)
+    assert not f0
+    lK, lk, lS = o0[9] + 0.05 * rng.standard_normal(o0[9].shape), o0[10] + 0.05, 1.5 * o0[11]
+    mu0, R = rng.standard_normal(n), rng.standard_normal((n, n))
+    s0 = 1e-2 * (R.T @ R / n + np.eye(n))
+    cost = [q[k] for k in ("Cxx", "cx", "Cuu", "cu", "Cxu", "c0")]
+    ag = O.gps_augment_cost(*cost, lK, lk, lS, q["alpha"], n, m, T)
+    agl = O.gps_augment_cost(*cost, lK, lk, lS, q["alpha"], n, m, T, long_double=True)
+    agm = M.gps_augment_cost(*cost, lK, lk, lS, q["alpha"], n, m, T)
+    for a, b, c in zip(ag, agl, agm):
+        assert rel(a, b) < 1e-11 and rel(a, c) < 1e-10, name
+    dyn = [q[k] for k in ("A", "B", "c", "sigma_dyn")]
+    bw, failed = O.gps_backward_pass(*ag, *dyn, q["alpha"], n, m, T)
+    bwl, _ = O.gps_backward_pass(*ag, *dyn, q["alpha"], n, m, T, long_double=True)
+    bwm = M.gps_backward_pass(*ag, *dyn, q["alpha"], n, m, T)
+    assert not failed
+    for k, a, b in zip(O.GPS_OUT, bw[:12], bwl[:12]):
+        assert rel(a, b) < 1e-10 and rel(a, bwm[k]) < 1e-10, (name, k, rel(a, b), rel(a, bwm[k]))
+    fw = O.gps_forward_pass(mu0, s0, *dyn, bw[9], bw[10], bw[11], n, m, T)
+    fwl = O.gps_forward_pass(mu0, s0, *dyn, bw[9], bw[10], bw[11], n, m, T, long_double=True)
+    fwm = M.gps_forward_pass(mu0, s0, *dyn, bw[9], bw[10], bw[11], n, m, T)
+    for a, b, c in zip(fw, fwl, fwm):
+        assert rel(a, b) < 1e-10 and rel(a, c) < 1e-10, name
+    dual = O.gps_quad_expectation(mu0, s0, bw[6][..., 0], bw[7][:, 0], bw[8][0])
+    assert abs(dual - M.gps_quad_expectation(mu0, s0, bw[6][..., 0], bw[7][:, 0], bw[8][0])) < 1e-10 * abs(dual)
+    kl = O.gps_kl_divergence(bw[9], bw[10], bw[11], lK, lk, lS, fw[0], fw[1], n, m, T)
+    klm = M.gps_kl_divergence(bw[9], bw[10], bw[11], lK, lk, lS, fw[0], fw[1], n, m, T)
+    assert rel(kl, klm) < 1e-9, (name, rel(kl, klm))
+    d = {"in_" + k: v for k, v in q.items()}
+    d.update(last_K=lK, last_kff=lk, last_sigma=lS, mu0=mu0, sigma0=s0, n=n, m=m, T=T, dual=dual, kl=kl)
+    d.update({"ag_" + k: v for k, v in zip(("Cxx", "cx", "Cuu", "cu", "Cxu", "c0"), ag)})
+    d.update({"bw_" + k: v for k, v in zip(O.GPS_OUT, bw[:12])})
+    d.update({"fw_" + k: v for k, v in zip(("mu_x", "sigma_x", "mu_u", "sigma_u", "mu_xu", "sigma_xu"), fw)})
+    np.savez(os.path.join(HERE, name + ".npz"), **d)
+
+
+def bsp_case(name, b, m, T, lmbda, reg, seed):
+    """bspilqr/src/util.cpp:83-204 (tau_mode 0: the intended tau.col(i+1) at :158)."""
+    q = S.problem(S.bsp_inputs(b, m, T, 1, seed=seed, coupling=5e-2), 0)
+    a = [q[k] for k in O.BSP_ARGS]
+    o, failed = O.bsp_backward_pass(*a, lmbda, reg, b, m, T)
+    ld, _ = O.bsp_backward_pass(*a, lmbda, reg, b, m, T, long_double=True)
+    mi = M.bsp_backward_pass(*a, lmbda, reg, b, m, T)
+    assert not failed
+    names = ("S", "s", "tau", "dS", "K", "kff")
+    for k, x, y in zip(names, o[:6], ld[:6]):
+        assert rel(x, y) < 1e-10 and rel(x, mi[k]) < 1e-10, (name, k)
+    d = {"in_" + k: v for k, v in q.items()}
+    d.update({"out_" + k: v for k, v in zip(names, o[:6])})
+    d.update(lmbda=lmbda, reg=reg, b=b, m=m, T=T)
+    np.savez(os.path.join(HERE, name + ".npz"), **d)
+
+
 if __name__ == "__main__":
     backward_case("bwd_c1_pendulum_2x1_T100", 2, 1, 100, 1.0, 1, 1337)
     backward_case("bwd_c2_cartpole_4x1_T64", 4, 1, 64, 1.0, 1, 1338)
@@ -94,6 +156,10 @@ if __name__ == "__main__":
     riccati_case("ric_6x2_T40", 6, 2, 40, 1343)
     ilqr_case("ilqr_pendulum_T40", "pendulum", 40, 6, 1344, dt=0.05, uw=[1e-5])
     ilqr_case("ilqr_cartpole_T30", "cartpole", 30, 4, 1345, dt=0.02, uw=[1e-5])
+    gps_case("gps_dual_4x1_T30", 4, 1, 30, 1346)
+    gps_case("gps_dual_4x2_T20", 4, 2, 20, 1347)
+    bsp_case("bsp_2x2_T30", 2, 2, 30, 0.5, 1, 1348)
+    bsp_case("bsp_4x2_T12", 4, 2, 12, 0.5, 2, 1349)
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -15,11 +15,19 @@ KEYS = ("Cxx", "cx", "Cuu", "cu", "Cxu", "A", "B")
 BWD = sorted(glob.glob(os.path.join(HERE, "bwd_*.npz")))
 RIC = sorted(glob.glob(os.path.join(HERE, "ric_*.npz")))
 ILQR = sorted(glob.glob(os.path.join(HERE, "ilqr_*.npz")))
+GPS = sorted(glob.glob(os.path.join(HERE, "gps_*.npz")))
+BSP = sorted(glob.glob(os.path.join(HERE, "bsp_*.npz")))
+GPS_ARGS = ("Cxx", "cx", "Cuu", "cu", "Cxu", "c0", "A", "B", "c", "sigma_dyn", "alpha")
+GPS_OUT = ("Qxx", "Qux", "Quu", "qx", "qu", "q0", "V", "v", "v0", "K", "kff", "sigma_ctl")
+AG = ("Cxx", "cx", "Cuu", "cu", "Cxu", "c0")
+FW = ("mu_x", "sigma_x", "mu_u", "sigma_u", "mu_xu", "sigma_xu")
+BSP_ARGS = ("Q", "q", "R", "r", "P", "p", "F", "G", "T", "U", "V", "X", "Y", "Z")
+BSP_OUT = ("S", "s", "tau", "dS", "K", "kff")
 ids = lambda fs: [os.path.basename(f)[:-4] for f in fs]
 
 
 def test_fixture_set_is_complete():
-    assert len(BWD) == 5 and len(RIC) == 2 and len(ILQR) == 2
+    assert len(BWD) == 5 and len(RIC) == 2 and len(ILQR) == 2 and len(GPS) == 2 and len(BSP) == 2
 
 
 @pytest.mark.parametrize("path", BWD, ids=ids(BWD))
@@ -112,3 +120,69 @@ def test_hip_ilqr_reproduces_fixture(path):
     st, ac, co = s.forward_pass(lc, float(g["fp_alpha"]))
     assert_close(st, g["fp_state"], "state"); assert_close(ac, g["fp_action"], "action")
     assert_close(co, g["fp_cost"], "cost")
+
+
+# ---- SURVEY 8f.2 / 8f.4 fixtures: one MBGPS dual evaluation; the belief-space backward pass -------------------------
+def _gps_chain(g, mod):
+    """The five functions of gps/src/util.cpp chained as gps/mbgps.py:173-195 does, through `mod`'s namesakes."""
+    n, m, T = int(g["n"]), int(g["m"]), int(g["T"])
+    last = (g["last_K"], g["last_kff"], g["last_sigma"])
+    ag = mod["augment_cost"](*[g["in_" + k] for k in AG], *last, g["in_alpha"], n, m, T)
+    bw = mod["backward_pass"](*ag, g["in_A"], g["in_B"], g["in_c"], g["in_sigma_dyn"], g["in_alpha"], n, m, T)
+    fw = mod["forward_pass"](g["mu0"], g["sigma0"], g["in_A"], g["in_B"], g["in_c"], g["in_sigma_dyn"], bw[9], bw[10],
+                             bw[11], n, m, T)
+    dual = mod["quad_expectation"](g["mu0"], g["sigma0"], bw[6][..., 0], bw[7][:, 0], bw[8][0])
+    kl = mod["kl_divergence"](bw[9], bw[10], bw[11], *last, fw[0], fw[1], n, m, T)
+    return ag, bw, fw, dual, kl
+
+
+def _check_gps(g, ag, bw, fw, dual, kl, tol):
+    for k, a in zip(AG, ag):
+        assert_close(a, g["ag_" + k], "ag_" + k, tol=tol)
+    for k, a in zip(GPS_OUT, bw[:12]):
+        assert_close(a, g["bw_" + k], "bw_" + k, tol=tol)
+    for k, a in zip(FW, fw):
+        assert_close(a, g["fw_" + k], "fw_" + k, tol=tol)
+    assert abs(dual - float(g["dual"])) <= tol * abs(float(g["dual"]))
+    assert_close(kl, g["kl"], "kl", tol=10 * tol)   # differences of nearly equal gains
+
+
+@pytest.mark.parametrize("path", GPS, ids=ids(GPS))
+def test_oracle_reproduces_gps_fixture(oracle, path):
+    g = np.load(path)
+    mod = dict(augment_cost=oracle.gps_augment_cost, forward_pass=oracle.gps_forward_pass,
+               backward_pass=lambda *a: oracle.gps_backward_pass(*a)[0], quad_expectation=oracle.gps_quad_expectation,
+               kl_divergence=oracle.gps_kl_divergence)
+    _check_gps(g, *_gps_chain(g, mod), tol=1e-13)
+
+
+@pytest.mark.parametrize("path", BSP, ids=ids(BSP))
+def test_oracle_reproduces_bsp_fixture(oracle, path):
+    g = np.load(path)
+    b, m, T = int(g["b"]), int(g["m"]), int(g["T"])
+    out, failed = oracle.bsp_backward_pass(*[g["in_" + k] for k in BSP_ARGS], float(g["lmbda"]), int(g["reg"]), b, m, T)
+    assert not failed
+    for k, a in zip(BSP_OUT, out[:6]):
+        assert_close(a, g["out_" + k], k, tol=1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GPS, ids=ids(GPS))
+def test_hip_gps_module_reproduces_fixture(path):
+    from trajopt_amd.gps import core
+    g = np.load(path)
+    mod = dict(augment_cost=core.augment_cost, forward_pass=core.forward_pass, backward_pass=core.backward_pass,
+               quad_expectation=core.quad_expectation, kl_divergence=lambda *a: core.kl_divergence(*a)[0])
+    _check_gps(g, *_gps_chain(g, mod), tol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", BSP, ids=ids(BSP))
+def test_hip_bsp_backward_reproduces_fixture(path):
+    from trajopt_amd.bspilqr.core import backward_pass
+    g = np.load(path)
+    b, m, T = int(g["b"]), int(g["m"]), int(g["T"])
+    out = backward_pass(*[g["in_" + k] for k in BSP_ARGS], float(g["lmbda"]), int(g["reg"]), b, m, T)
+    assert out[6] == 0
+    for k, a in zip(BSP_OUT, out[:6]):
+        assert_close(a, g["out_" + k], k)
