@@ -115,9 +115,22 @@ __global__ void select_kernel(DrvArgs a) {
     const double dV0 = a.ws.dV[p], dV1 = a.ws.dV[NP + p];
     int sel = -1;
     double best = 0.0, dret_sel = 0.0, alpha_last = a.ws.alpha[p];
+    // the first 16 returns are fetched up front: behind the loop's early exit they were one dependent L2 round trip
+    // per step size (this kernel is nothing but that latency)
+    constexpr int kPre = 16;
+    double pre[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) pre[k] = k < a.opt.nb_alphas ? a.ws.cand_ret[(size_t)k * NP + p] : 0.0;
     for (int k = 0; k < a.opt.nb_alphas; ++k) {
         const double alpha = a.opt.alphas[k];
-        const double ret = a.ws.cand_ret[(size_t)k * NP + p];
+        double ret;
+        if (k < kPre) {
+            ret = pre[0];
+#pragma unroll
+            for (int j = 1; j < kPre; ++j) ret = (k == j) ? pre[j] : ret;
+        } else {
+            ret = a.ws.cand_ret[(size_t)k * NP + p];
+        }
         const double dret = last - ret;
         const double expected = -1.0 * alpha * (dV0 + alpha * dV1);
         const double imp = dret / expected;
