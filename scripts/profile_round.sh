@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU call's worth of measurements for profiles/: kernel trace of the bench command, the two PMC passes,
-# the backward pass alone on C1-C5, and the bench at 65 536 instances.  Run from the repo root on the GPU box.
+# the backward pass alone on C1-C5, the bench at 65 536 instances and at C3's 8192 double cartpoles, and the GPS / belief-space rows.  Run from the repo root on the GPU box.
 set -o pipefail
 export TMPDIR=/tmp
 O=gpurun_out/prof
@@ -18,4 +18,6 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_wri
 } > $O/backward_all_configs.log 2>&1
 timeout -k 10 200 python bench.py --no-cpu-baseline --instances 65536 --steps 5 --warmup 2 > $O/bench_65536.json 2> $O/bench_65536.err || exit 1
 timeout -k 10 200 python bench.py --no-cpu-baseline --env double_cartpole --instances 8192 --steps 5 --warmup 2 > $O/bench_c3.json 2> $O/bench_c3.err || exit 1
+PYTHONPATH=. timeout -k 10 200 python -u scripts/bench_gps.py $O/gps_bench.json > $O/gps_bench.log 2>&1 || exit 1
+PYTHONPATH=. timeout -k 10 200 python -u scripts/bench_bsp.py $O/bsp_bench.json > $O/bsp_bench.log 2>&1 || exit 1
 echo done
