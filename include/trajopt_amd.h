@@ -184,7 +184,8 @@ int trajopt_gps_backward_pass_host(const double* Cxx_host, const double* cx_host
  *   augment_cost      util.cpp:136-193 (mbgps.py:166-170)   cost + alpha * log-policy terms; T+1 slices, the last copied
  *   kl_divergence     util.cpp:83-121  (mbgps.py:198-201)   per-step KL(p || q) of two linear-Gaussian controllers
  *   quad_expectation  util.cpp:123-134 (mbgps.py:184-186)   E[x'Qx + x'q + q0] under N(mu, sigma)
- * status[p] = 1 when a sigma_ctl is not positive definite (Armadillo's inv_sympd() throws there), else 0. */
+ * status[p] = 1 when a sigma_ctl is not positive definite (Armadillo's inv_sympd() throws there), else 0.
+ * augment_cost and kl_divergence launch one grid row per step: nb_steps < 65535 (TRAJOPT_ERR_BAD_ARG beyond). */
 int trajopt_gps_forward_pass_batched(const double* mu_x0, const double* sigma_x0, const double* A, const double* B,
                                      const double* c, const double* sigma_dyn, const double* K, const double* kff,
                                      const double* sigma_ctl, int dm_state, int dm_act, int nb_steps,
