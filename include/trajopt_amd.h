@@ -372,6 +372,9 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
 #define TRAJOPT_PROFILE_PHASES 6
 int trajopt_profile_begin(int max_iterations);
 int trajopt_profile_end(double* phase_ms, int* nb_iterations);
+/* after trajopt_profile_begin: bracket only the phases in phase_mask (bit k = phase k; others report 0) - an event costs
+ * the stream about 5 us, so a timed region should carry only the ones it needs */
+int trajopt_profile_select(unsigned phase_mask);
 
 /* Layout conversion helper (device to device): dst = src re-laid-out; rows*cols*slices elements/problem. */
 int trajopt_convert_layout(const double* src, double* dst, int64_t elems_per_problem, int64_t nb_problems,

@@ -100,7 +100,7 @@ EXPORTS = (
     "trajopt_riccati_backward_pass_host", "trajopt_riccati_backward_pass_batched",
     "trajopt_env_step_batched", "trajopt_ilqr_forward_pass_batched", "trajopt_quadratize_batched",
     "trajopt_ilqr_init_rollout", "trajopt_ilqr_iterate", "trajopt_convert_layout",
-    "trajopt_profile_begin", "trajopt_profile_end",
+    "trajopt_profile_begin", "trajopt_profile_end", "trajopt_profile_select",
 )
 
 _lib = None
