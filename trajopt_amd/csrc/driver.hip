@@ -59,12 +59,16 @@ __global__ void init_select_kernel(DrvArgs a) {
     a.ws.iters[p] = 0;
 }
 
-__global__ void prep_kernel(DrvArgs a) {
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= (size_t)a.ws.nb_problems) return;
+// Start of an iteration (ilqr.py:151): a problem takes part while its status is 0.
+__device__ __forceinline__ void prep_problem(const DrvArgs& a, size_t p) {
     const int act = a.ws.status[p] == 0 ? 1 : 0;
     a.ws.active[p] = act;
     if (act) a.ws.iters[p] += 1;
+}
+__global__ void prep_kernel(DrvArgs a) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)a.ws.nb_problems) return;
+    prep_problem(a, p);
 }
 
 // ilqr.py:175-180 plus the "backward pass gave up" path (:168 -> :224-231).
@@ -105,10 +109,17 @@ __global__ void pending_kernel(DrvArgs a) {
 }
 
 // ilqr.py:187-231: sequential first-accept over the alphas, evaluated from the precomputed returns.
-__global__ void select_kernel(DrvArgs a) {
+// prep_next: another iteration follows in this call - its prep (same thread-per-problem mapping, nothing reads `active`
+// in between) is done here instead of in a launch of its own.
+__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP);
+__global__ void select_kernel(DrvArgs a, int prep_next) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t NP = (size_t)a.ws.nb_problems;
     if (p >= NP) return;
+    select_problem(a, p, NP);
+    if (prep_next) prep_problem(a, p);
+}
+__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP) {
     a.ws.sel[p] = -1;
     if (!a.ws.active[p]) return;
     const double last = a.ws.last_return[p];
@@ -343,7 +354,7 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
     for (int it = 0; it < nb_iter; ++it) {
         const int slot = (g_prof.on && g_prof.used < g_prof.cap) ? g_prof.used++ : -1;
         prof_mark(st, slot, 0);
-        hipLaunchKernelGGL(prep_kernel, dim3(g1), dim3(256), 0, st, a);
+        if (it == 0) hipLaunchKernelGGL(prep_kernel, dim3(g1), dim3(256), 0, st, a);   // later ones ride in select_kernel
         prof_mark(st, slot, 1);
         // The accepted candidate of iteration it-1 is promoted to xref/uref/K/kff by this iteration's
         // quadratisation (it reads every (problem, step) of the trajectory anyway); only the last iteration
@@ -380,7 +391,7 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
             if (rc != TRAJOPT_OK) return rc;
         }
         prof_mark(st, slot, 5);
-        hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a, it + 1 < nb_iter ? 1 : 0);
         if (!fuse_commit || it == nb_iter - 1) {
             if (gminor) hipLaunchKernelGGL(commit_kernel<true>, g2, dim3(256), 0, st, a, 1);
             else hipLaunchKernelGGL(commit_kernel<false>, g2, dim3(256), 0, st, a, 1);
