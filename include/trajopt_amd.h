@@ -40,6 +40,7 @@ extern "C" {
 #define TRAJOPT_ERR_UNSUPPORTED (-2)  /* shape outside what the kernels are built for             */
 #define TRAJOPT_ERR_HIP (-3)          /* a HIP runtime call failed; see trajopt_last_hip_error()  */
 #define TRAJOPT_ERR_NO_DEVICE (-4)    /* no usable GPU: there is no CPU fallback by design        */
+#define TRAJOPT_ERR_TOO_LARGE (-5)    /* beyond the static staging of an allocation-free entry    */
 
 #define TRAJOPT_LAYOUT_PROBLEM_MAJOR 0
 #define TRAJOPT_LAYOUT_PROBLEM_MINOR 1
@@ -80,6 +81,27 @@ int trajopt_ilqr_backward_pass_host(const double* Cxx_host, const double* cx_hos
                                     double* qx_host, double* qu_host, double* V_host, double* v_host,
                                     double* dV_host, double* K_host, double* kff_host, int* diverge,
                                     int* failed);
+
+/* Allocation-free variant of trajopt_ilqr_backward_pass_host.  It has NO counterpart in the reference: it is for
+ * callers that cannot allocate device memory - code under HIP graph capture, tight serving / MPC loops, harnesses
+ * that forbid hipMalloc.  Same arguments, results and kernels as trajopt_ilqr_backward_pass_host, plus the stream
+ * the copies and kernels run on (NULL = the default stream; the call synchronises that stream before returning).
+ * The device staging (inputs | outputs | lmbda, diverge) lives in a static device array of the library of
+ * TRAJOPT_NOALLOC_MAX_DOUBLES doubles (4 MiB, held per GPU until the process ends) instead of hipMalloc/hipFree:
+ * the call performs no allocation of any kind.  A problem needing more staging than that
+ * (trajopt_ilqr_backward_pass_host_noalloc_doubles(n, m, T) > TRAJOPT_NOALLOC_MAX_DOUBLES; the limit covers
+ * BASELINE's C1-C4 shapes at T = 500, e.g. 12 x 4 x 500 needs 424 384) is rejected with TRAJOPT_ERR_TOO_LARGE before any
+ * device work.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU (two host threads, or
+ * two streams) race - serialise them. */
+#define TRAJOPT_NOALLOC_MAX_DOUBLES 524288
+int64_t trajopt_ilqr_backward_pass_host_noalloc_doubles(int dm_state, int dm_act, int nb_steps);
+int trajopt_ilqr_backward_pass_host_noalloc(const double* Cxx_host, const double* cx_host, const double* Cuu_host,
+                                            const double* cu_host, const double* Cxu_host, const double* A_host,
+                                            const double* B_host, double lmbda, int reg, int dm_state, int dm_act,
+                                            int nb_steps, double* Qxx_host, double* Qux_host, double* Quu_host,
+                                            double* qx_host, double* qu_host, double* V_host, double* v_host,
+                                            double* dV_host, double* K_host, double* kff_host, int* diverge,
+                                            int* failed, void* stream);
 
 typedef struct trajopt_backward_io {
     /* inputs (ilqr.py:112-114): cost arrays have nb_steps+1 slices, A/B have nb_steps */

@@ -91,6 +91,7 @@ class ILQRWorkspace(C.Structure):
 EXPORTS = (
     "trajopt_abi_version", "trajopt_error_string", "trajopt_last_hip_error", "trajopt_device_count",
     "trajopt_ilqr_backward_pass_host", "trajopt_ilqr_backward_pass_batched",
+    "trajopt_ilqr_backward_pass_host_noalloc", "trajopt_ilqr_backward_pass_host_noalloc_doubles",
     "trajopt_backward_supports_structured_cost",
     "trajopt_gps_backward_supported", "trajopt_gps_backward_pass_batched", "trajopt_gps_backward_pass_host",
     "trajopt_gps_forward_pass_batched", "trajopt_gps_augment_cost_batched", "trajopt_gps_kl_divergence_batched",

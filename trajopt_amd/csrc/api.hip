@@ -3,6 +3,7 @@
 // compute entry point returns TRAJOPT_ERR_NO_DEVICE / TRAJOPT_ERR_HIP.
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "common.h"
@@ -65,6 +66,7 @@ const char* trajopt_error_string(int code) {
         case TRAJOPT_ERR_UNSUPPORTED: return "unsupported shape";
         case TRAJOPT_ERR_HIP: return "HIP runtime error";
         case TRAJOPT_ERR_NO_DEVICE: return "no HIP device (there is no CPU fallback)";
+        case TRAJOPT_ERR_TOO_LARGE: return "problem exceeds the static device staging of the allocation-free entry point";
         default: return "unknown error";
     }
 }
@@ -171,40 +173,44 @@ int trajopt_convert_layout(const double* src, double* dst, int64_t E, int64_t NP
 }
 
 // ---- host-pointer wrappers: the exact shape of the reference's pybind11 entry ------------------------
-int trajopt_ilqr_backward_pass_host(const double* Cxx, const double* cx, const double* Cuu, const double* cu,
-                                    const double* Cxu, const double* A, const double* B, double lmbda, int reg,
-                                    int n, int m, int T, double* Qxx, double* Qux, double* Quu, double* qx,
-                                    double* qu, double* V, double* v, double* dV, double* K, double* kff,
-                                    int* diverge, int* failed) {
-    if (!Cxx || !cx || !Cuu || !cu || !Cxu || !A || !B || !Qxx || !Qux || !Quu || !qx || !qu || !V || !v || !dV ||
-        !K || !kff || !diverge)
-        return TRAJOPT_ERR_BAD_ARG;
-    if (n <= 0 || m <= 0 || T <= 0) return TRAJOPT_ERR_BAD_ARG;
-    if (trajopt_device_count() < 0) return TRAJOPT_ERR_NO_DEVICE;
+}  // extern "C"
+
+namespace trajopt {
+
+// doubles of device staging one host-array backward pass needs: inputs | outputs | lmbda, diverge
+static size_t backward_host_staging_doubles(int n, int m, int T) {
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m, T1 = (size_t)T + 1;
+    return (nn + n + mm + m + nm) * T1 + (nn + nm) * (size_t)T               // Cxx cx Cuu cu Cxu | A B
+           + (nn + nm + mm + n + m + nm + m) * (size_t)T + (nn + n) * T1 + 2  // Qxx Qux Quu qx qu K kff | V v | dV
+           + 2;                                                               // lmbda, diverge
+}
+
+// The body shared by trajopt_ilqr_backward_pass_host (staging from hipMalloc) and its allocation-free variant
+// (staging = the library's static device array): copy in, zero the outputs, run the batched kernels, copy out.
+static int backward_host_on_staging(double* staging, hipStream_t st, const double* Cxx, const double* cx,
+                                    const double* Cuu, const double* cu, const double* Cxu, const double* A,
+                                    const double* B, double lmbda, int reg, int n, int m, int T, double* Qxx,
+                                    double* Qux, double* Quu, double* qx, double* qu, double* V, double* v,
+                                    double* dV, double* K, double* kff, int* diverge, int* failed) {
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
-    // one allocation: inputs | outputs | scalars
     const size_t in_counts[7] = {nn * (T + 1), (size_t)n * (T + 1), mm * (T + 1), (size_t)m * (T + 1), nm * (T + 1),
                                  nn * T, nm * T};
     const double* in_host[7] = {Cxx, cx, Cuu, cu, Cxu, A, B};
     const size_t out_counts[10] = {nn * T, nm * T, mm * T, (size_t)n * T, (size_t)m * T, nn * (T + 1),
                                    (size_t)n * (T + 1), 2, nm * T, (size_t)m * T};
     double* out_host[10] = {Qxx, Qux, Quu, qx, qu, V, v, dV, K, kff};
-    size_t total = 0;
-    for (size_t c : in_counts) total += c;
-    size_t in_total = total;
-    for (size_t c : out_counts) total += c;
-    total += 2;  // lmbda, (int) diverge
-    DevBuf buf;
-    TRAJOPT_HIP_CHECK(buf.alloc(total));
-    hipStream_t st = nullptr;
-    double* d = buf.p;
+    size_t in_total = 0;
+    for (size_t c : in_counts) in_total += c;
+    const size_t total = backward_host_staging_doubles(n, m, T);
+    double* d = staging;
     const double* din[7];
     for (int i = 0; i < 7; ++i) {
         TRAJOPT_HIP_CHECK(hipMemcpyAsync(d, in_host[i], in_counts[i] * sizeof(double), hipMemcpyHostToDevice, st));
         din[i] = d;
         d += in_counts[i];
     }
-    TRAJOPT_HIP_CHECK(hipMemsetAsync(buf.p + in_total, 0, (total - in_total) * sizeof(double), st));
+    // the staging keeps whatever the previous call left: every output (and the diverge word) starts at zero
+    TRAJOPT_HIP_CHECK(hipMemsetAsync(staging + in_total, 0, (total - in_total) * sizeof(double), st));
     double* dout[10];
     for (int i = 0; i < 10; ++i) {
         dout[i] = d;
@@ -229,6 +235,84 @@ int trajopt_ilqr_backward_pass_host(const double* Cxx, const double* cx, const d
     *diverge = div < 0 ? 0 : div;  // util.cpp:120,146
     if (failed) *failed = div >= 0 ? 1 : 0;
     return TRAJOPT_OK;
+}
+
+}  // namespace trajopt
+
+extern "C" {
+
+int trajopt_ilqr_backward_pass_host(const double* Cxx, const double* cx, const double* Cuu, const double* cu,
+                                    const double* Cxu, const double* A, const double* B, double lmbda, int reg,
+                                    int n, int m, int T, double* Qxx, double* Qux, double* Quu, double* qx,
+                                    double* qu, double* V, double* v, double* dV, double* K, double* kff,
+                                    int* diverge, int* failed) {
+    if (!Cxx || !cx || !Cuu || !cu || !Cxu || !A || !B || !Qxx || !Qux || !Quu || !qx || !qu || !V || !v || !dV ||
+        !K || !kff || !diverge)
+        return TRAJOPT_ERR_BAD_ARG;
+    if (n <= 0 || m <= 0 || T <= 0) return TRAJOPT_ERR_BAD_ARG;
+    if (trajopt_device_count() < 0) return TRAJOPT_ERR_NO_DEVICE;
+    DevBuf buf;  // one allocation: inputs | outputs | scalars
+    TRAJOPT_HIP_CHECK(buf.alloc(backward_host_staging_doubles(n, m, T)));
+    return backward_host_on_staging(buf.p, nullptr, Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, n, m, T, Qxx, Qux, Quu,
+                                    qx, qu, V, v, dV, K, kff, diverge, failed);
+}
+
+// ---- allocation-free variant of trajopt_ilqr_backward_pass_host ----------------------------------------
+}  // extern "C"
+
+namespace trajopt {
+
+// Device staging of the allocation-free entry point: a file-scope array of the code object, one copy per GPU the
+// library runs on, held until the process ends.  In host code `scratch` is only a symbol: its per-device address
+// comes from hipGetSymbolAddress (below) and everything - copies, memset, kernel arguments - uses that pointer.
+constexpr size_t kStaticStagingDoubles = TRAJOPT_NOALLOC_MAX_DOUBLES;
+static __device__ __align__(256) double scratch[kStaticStagingDoubles];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static double* g_scratch_ptr[kMaxDevices] = {};   // [device ordinal] -> that device's copy of `scratch`
+
+// address of the current device's copy (resolved once per device, with that device current)
+static int static_staging(double** out) {
+    int dev = -1;
+    TRAJOPT_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return TRAJOPT_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        double* ptr = nullptr;
+        TRAJOPT_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+        if (!ptr) return TRAJOPT_ERR_HIP;
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return TRAJOPT_OK;
+}
+
+}  // namespace trajopt
+
+extern "C" {
+
+int64_t trajopt_ilqr_backward_pass_host_noalloc_doubles(int n, int m, int T) {
+    if (n <= 0 || m <= 0 || T <= 0) return TRAJOPT_ERR_BAD_ARG;
+    return (int64_t)backward_host_staging_doubles(n, m, T);
+}
+
+int trajopt_ilqr_backward_pass_host_noalloc(const double* Cxx, const double* cx, const double* Cuu, const double* cu,
+                                            const double* Cxu, const double* A, const double* B, double lmbda,
+                                            int reg, int n, int m, int T, double* Qxx, double* Qux, double* Quu,
+                                            double* qx, double* qu, double* V, double* v, double* dV, double* K,
+                                            double* kff, int* diverge, int* failed, void* stream) {
+    if (!Cxx || !cx || !Cuu || !cu || !Cxu || !A || !B || !Qxx || !Qux || !Quu || !qx || !qu || !V || !v || !dV ||
+        !K || !kff || !diverge)
+        return TRAJOPT_ERR_BAD_ARG;
+    if (n <= 0 || m <= 0 || T <= 0) return TRAJOPT_ERR_BAD_ARG;
+    if (backward_host_staging_doubles(n, m, T) > kStaticStagingDoubles) return TRAJOPT_ERR_TOO_LARGE;
+    if (trajopt_device_count() < 0) return TRAJOPT_ERR_NO_DEVICE;
+    double* staging = nullptr;
+    const int rc = static_staging(&staging);
+    if (rc != TRAJOPT_OK) return rc;
+    return backward_host_on_staging(staging, as_stream(stream), Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, n, m, T, Qxx,
+                                    Qux, Quu, qx, qu, V, v, dV, K, kff, diverge, failed);
 }
 
 int trajopt_riccati_backward_pass_host(const double* Cxx, const double* cx, const double* Cuu, const double* cu,
