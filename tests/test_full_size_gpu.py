@@ -117,3 +117,137 @@ def test_ilqr_iteration_full_size_c2(oracle):
         assert st[p] == r["status"] and lam[p] == pytest.approx(r["lmbda"], rel=1e-14)
         assert_close(xref[p], r["xref"], "xref", tol=1e-8)
         assert_close(uref[p], r["uref"], "uref", tol=1e-8)
+
+
+def _tiled_iteration(oracle, name, kw, N, D, T, iters, alphas, check_every, scale=1e-2, kff_bias=0.0):
+    """`N // D` copies of D distinct problems through `iters` full iterations: every copy bitwise the first, the
+    distinct ones against the oracle's driver (ilqr.py:136-237) with the same step sizes."""
+    from oracle import oracle as O
+    from trajopt_amd import envs
+    from trajopt_amd.ilqr import BatchedILQR
+    reps = N // D
+    pe = envs.make(name, **kw)
+    okw = dict(kw)
+    okw["uw"] = list(np.asarray(okw["uw"], dtype=float) * np.ones(pe.dm_act))
+    oe = O.make_env(name, **okw)
+    rng = np.random.Generator(np.random.PCG64(1337))
+    x0 = np.asarray(pe.x0)[None] + scale * rng.standard_normal((D, pe.dm_state))
+    kff0 = kff_bias + 1e-4 * rng.standard_normal((D, pe.dm_act, T))
+    s = BatchedILQR(pe, T, np.tile(x0, (reps, 1)), kff_init=np.tile(kff0, (reps, 1, 1)), action_penalty=None,
+                    apply_env_kwargs=False, alphas=alphas)
+    traces = s.run(nb_iter=iters)
+    xref, uref, ret, lam, st, al = (s.host(k) for k in ("xref", "uref", "last_return", "lmbda", "status", "alpha"))
+    for arr in (xref, uref, ret, lam, st, al):
+        v = arr.reshape((reps, D) + arr.shape[1:])
+        assert np.array_equal(v, np.broadcast_to(v[:1], v.shape), equal_nan=True), "copies differ"
+    for p in range(0, D, check_every):
+        r = oracle.ilqr_run(oe, T, x0[p], kff0[p], alphas=alphas, nb_iter=iters)
+        assert len(traces[p]) == len(r["trace"]), (p, traces[p], r["trace"])
+        assert_close(np.array(traces[p]), r["trace"], "trace[%d]" % p)
+        assert abs(ret[p] - r["last_return"]) <= TOL * abs(r["last_return"])
+        assert st[p] == r["status"] and lam[p] == pytest.approx(r["lmbda"], rel=1e-14)
+        assert_close(xref[p], r["xref"], "xref", tol=1e-8)
+        assert_close(uref[p], r["uref"], "uref", tol=1e-8)
+    return s
+
+
+def test_ilqr_iteration_full_size_c3(oracle):
+    """C3, one GPU's share: 8192 double cartpoles, T = 500, the reference's 11 step sizes; 128 copies of 64."""
+    from oracle import oracle as O
+    _tiled_iteration(oracle, "double_cartpole", dict(dt=0.01, uw=1e-5), 8192, 64, 500, 2, O.DEFAULT_ALPHAS, 8)
+
+
+def test_ilqr_iteration_full_size_c4_eight_alphas(oracle):
+    """C4 as BASELINE states it: 4096 quadrotors (dx = 12, du = 4), T = 500, the 8-alpha line search
+    10**linspace(0,-3,11)[:8]; 128 copies of 32 distinct problems.  The initial feed-forward is the hover
+    thrust m g / 4 per rotor (+ the reference's 1e-4 noise, ilqr.py:70): from kff ~ 0 the vehicle free-falls and tumbles
+    for the 10 s horizon, a chaotic rollout in which round-off alone decides which step size is accepted."""
+    from oracle import oracle as O
+    s = _tiled_iteration(oracle, "quadrotor", dict(dt=0.02, uw=1e-3), 4096, 32, 500, 3, O.DEFAULT_ALPHAS[:8], 4,
+                         kff_bias=0.5 * 9.81 / 4)
+    assert s.alphas.size == 8 and s._cand_state.shape[0] == 8
+
+
+def test_sharded_ilqr_world_size_one_is_the_batched_solver(oracle):
+    """ShardedILQR without a process group = BatchedILQR on the whole batch, bit for bit."""
+    from trajopt_amd import envs
+    from trajopt_amd.ilqr import BatchedILQR
+    from trajopt_amd.sharding import ShardedILQR
+    N, T, iters = 96, 60, 4
+    rng = np.random.Generator(np.random.PCG64(5))
+    x0 = np.array([0., np.pi, 0., 0.])[None] + 1e-2 * rng.standard_normal((N, 4))
+    kff0 = 1e-4 * rng.standard_normal((N, 1, T))
+    sh = ShardedILQR(envs.make("cartpole", dt=0.02), T, x0, kff_init=kff0, action_penalty=1e-5)
+    out = sh.run(nb_iter=iters)
+    b = BatchedILQR(envs.make("cartpole", dt=0.02), T, x0, kff_init=kff0, action_penalty=1e-5)
+    b.run(nb_iter=iters)
+    assert np.array_equal(out["last_return"].cpu().numpy(), b.host("last_return"))
+    assert np.array_equal(out["status"].cpu().numpy(), b.host("status"))
+    assert np.array_equal(out["iters"].cpu().numpy(), b.host("iters"))
+    assert np.array_equal(sh.local.host("xref"), b.host("xref"))
+    assert out["progress"]["total_cost"] == pytest.approx(float(b.host("last_return").sum()), rel=1e-12)
+    oe = oracle.make_env("cartpole", dt=0.02, uw=[1e-5])
+    for p in range(0, N, 19):
+        r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=iters)
+        assert abs(float(out["last_return"][p]) - r["last_return"]) <= TOL * abs(r["last_return"])
+
+
+def _sharded_rank(rank, world, port, N, T, iters, q):
+    """One rank of the 2-rank rehearsal: both ranks share the box's single GPU, so the process group is gloo
+    (RCCL refuses two ranks on one device) and the gathered vectors cross on the host."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    from trajopt_amd import envs
+    from trajopt_amd.sharding import ShardedILQR
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.Generator(np.random.PCG64(5))
+        x0 = np.array([0., np.pi, 0., 0.])[None] + 1e-2 * rng.standard_normal((N, 4))
+        kff0 = 1e-4 * rng.standard_normal((N, 1, T))
+        sh = ShardedILQR(envs.make("cartpole", dt=0.02), T, x0, kff_init=kff0, action_penalty=1e-5)
+        out = sh.run(nb_iter=iters)
+        q.put((rank, sh.lo, sh.hi, out["last_return"].cpu().numpy(), out["status"].cpu().numpy(),
+               out["iters"].cpu().numpy(), out["progress"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_ilqr_two_ranks_equal_one_rank():
+    """contiguous block split, no exchange during an iteration, gather at the end.  Two spawned ranks
+    (ragged split of 97 problems) must assemble exactly the single-rank result on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    from trajopt_amd import envs
+    from trajopt_amd.ilqr import BatchedILQR
+    N, T, iters, world = 97, 60, 4, 2
+    rng = np.random.Generator(np.random.PCG64(5))
+    x0 = np.array([0., np.pi, 0., 0.])[None] + 1e-2 * rng.standard_normal((N, 4))
+    kff0 = 1e-4 * rng.standard_normal((N, 1, T))
+    b = BatchedILQR(envs.make("cartpole", dt=0.02), T, x0, kff_init=kff0, action_penalty=1e-5)
+    b.run(nb_iter=iters)
+    want = {k: b.host(k).copy() for k in ("last_return", "status", "iters")}
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_rank, args=(r, world, port, N, T, iters, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted((g[1], g[2]) for g in got) == [(0, 49), (49, 97)]
+    for rank, lo, hi, ret, st, it, prog in got:
+        assert np.array_equal(ret, want["last_return"]) and np.array_equal(st, want["status"])
+        assert np.array_equal(it, want["iters"])
+        assert prog["total_cost"] == pytest.approx(float(want["last_return"].sum()), rel=1e-12)
+        assert prog["nb_stopped"] == int((want["status"] != 0).sum())

@@ -380,3 +380,88 @@ def test_staged_line_search_is_bitwise_the_one_launch_line_search(oracle, name, 
     for p in range(0, N, 37):
         r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=6)
         assert abs(res[1]["last_return"][p] - r["last_return"]) <= TOL * abs(r["last_return"])
+
+
+@pytest.mark.parametrize("name,gl", [("quadrotor", None), ("cartpole", 0), ("cartpole", 1)])
+def test_driver_reads_dV_in_the_gains_layout(oracle, name, gl):
+    """The line search's expected reduction -alpha (dV[0] + alpha dV[1]) (ilqr.py:195) must use THIS problem's dV:
+    the backward kernels store dV with the gains group's layout ((N, 2) for PROBLEM_MAJOR, (2, N) for MINOR).
+    min_imp > 0 makes the accept decision depend on the magnitude of `expected`, not only on its sign."""
+    from trajopt_amd.ilqr import BatchedILQR
+    pe, oe = _pair(name, dt=0.02)
+    N, T = 7, 40
+    rng = np.random.Generator(np.random.PCG64(99))
+    x0 = np.asarray(pe.x0)[None] + 0.1 * rng.standard_normal((N, pe.dm_state))
+    kff0 = (0.5 * 9.81 / 4 if name == "quadrotor" else 0.0) + 1e-2 * rng.standard_normal((N, pe.dm_act, T))
+    s = BatchedILQR(pe, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False, gains_layout=gl, min_imp=0.3)
+    s.init_rollout()
+    xr, ur = s.host("xref").copy(), s.host("uref").copy()
+    s.iterate(1)
+    dV = s._dV.cpu().numpy()
+    dV = dV.T if s.gains_layout == 1 else dV          # -> (N, 2)
+    for p in range(N):
+        q = oracle.quadratize(oe, T, xr[p], ur[p], np.ones(T + 1))
+        rb, failed = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], 1.0, 1,
+                                          pe.dm_state, pe.dm_act, T)
+        assert not failed
+        assert_close(dV[p], rb[7], "dV[%d]" % p)
+    traces = s.run(nb_iter=3)
+    for p in range(N):
+        r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=4, min_imp=0.3)
+        assert len(traces[p]) == len(r["trace"]), (p, traces[p], r["trace"])
+        assert_close(np.array(traces[p]), r["trace"], "trace[%d]" % p)
+        assert s.host("alpha")[p] == pytest.approx(r["alpha"], rel=1e-14, nan_ok=True)
+
+
+def test_trace_keeps_every_accepted_return_beyond_the_initial_capacity(oracle):
+    """ilqr.py:219 appends every accepted return: the device trace buffer grows instead of dropping entries, across
+    repeated iterate() calls and in the drop-in class with nb_iter > 100."""
+    from trajopt_amd import envs
+    from trajopt_amd.ilqr import BatchedILQR, iLQR
+    pe, oe = _pair("cartpole", dt=0.02, uw=[1e-5])
+    N, T = 5, 40
+    rng = np.random.Generator(np.random.PCG64(3))
+    x0 = np.asarray(pe.x0)[None] + 1e-2 * rng.standard_normal((N, 4))
+    kff0 = 1e-4 * rng.standard_normal((N, 1, T))
+    s = BatchedILQR(pe, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False, trace_cap=3)
+    s.init_rollout()
+    for _ in range(4):
+        s.iterate(3)
+    traces = s.run(nb_iter=0)
+    assert s.trace_cap >= 13
+    for p in range(N):
+        r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=12)
+        assert len(r["trace"]) > 3 and len(traces[p]) == len(r["trace"])
+        assert_close(np.array(traces[p]), r["trace"], "trace[%d]" % p)
+    env = envs.make("LQR-TO-v0")
+    np.random.seed(5)
+    kw = dict(tolfun=-np.inf, tolgrad=0.0, max_lmbda=np.inf)
+    solver = iLQR(env, nb_steps=30, init_state=np.array([1.0, -0.5]), action_penalty=np.array([1e-2]), **kw)
+    kff = solver.ctl.kff.copy()
+    trace = solver.run(nb_iter=130)
+    ref = oracle.ilqr_run(oracle.make_env("lqr", uw=[1e-2]), 30, np.array([1.0, -0.5]), kff, nb_iter=130, **kw)
+    assert len(trace) == len(ref["trace"]) and len(trace) > 101
+    assert_close(np.array(trace[:5]), ref["trace"][:5], "trace head")
+
+
+def test_reset_takes_torch_and_numpy_kff_alike(oracle):
+    """BatchedILQR.reset(kff_init=...) takes the logical (N, m, T) array whether it is NumPy or torch, in both gains
+    layouts (BatchedMPC forwards kff_inits[t] unchanged)."""
+    import torch
+    from trajopt_amd import envs
+    from trajopt_amd.ilqr import BatchedILQR
+    for name, gl in (("double_pendulum", 1), ("double_pendulum", 0)):
+        pe = envs.make(name, dt=0.02)
+        N, T, m = 6, 25, pe.dm_act
+        rng = np.random.Generator(np.random.PCG64(8))
+        x0 = np.asarray(pe.x0)[None] + 1e-2 * rng.standard_normal((N, pe.dm_state))
+        kff0 = 1e-2 * rng.standard_normal((N, m, T))
+        s = BatchedILQR(pe, T, x0, kff_init=np.zeros((N, m, T)), action_penalty=1e-5, gains_layout=gl)
+        out = []
+        for k in (kff0, torch.as_tensor(kff0), torch.as_tensor(kff0, device="cuda")):
+            s.reset(x0, kff_init=k)
+            assert np.array_equal(s.host("kff"), kff0)
+            s.run(nb_iter=2)
+            out.append((s.host("last_return").copy(), s.host("uref").copy()))
+        for o in out[1:]:
+            assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])

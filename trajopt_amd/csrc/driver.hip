@@ -41,14 +41,23 @@ __device__ __forceinline__ void shrink_lambda(double& lam, double& dlam, const t
     lam = lam * dlam * (lam > s.min_lmbda ? 1.0 : 0.0);    // ilqr.py:179 / :208
 }
 
-// ilqr.py:139-149: first alpha whose whole state trajectory is < 1e8 becomes the reference.
+// dV = [kff'qu, 1/2 kff'Quu kff] (util.cpp:154) of problem p as the backward kernels store it: dV belongs to the gains
+// group, so it is (2, NP) struct-of-arrays for PROBLEM_MINOR and (NP, 2) for PROBLEM_MAJOR.
+__device__ __forceinline__ void load_dV(const DrvArgs& a, size_t p, size_t NP, double& dV0, double& dV1) {
+    const bool gminor = a.ws.gains_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
+    dV0 = a.ws.dV[gminor ? p : 2 * p];
+    dV1 = a.ws.dV[gminor ? NP + p : 2 * p + 1];
+}
+
+// ilqr.py:139-149: first alpha whose whole state trajectory is < 1e8 becomes the reference.  The return must also be
+// finite: all(state < 1e8) lets -inf / hugely negative states through, whose cost the device sincos reports as NaN.
 __global__ void init_select_kernel(DrvArgs a) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t NP = (size_t)a.ws.nb_problems;
     if (p >= NP) return;
     int sel = -1;
     for (int k = 0; k < a.opt.nb_alphas; ++k)
-        if (a.ws.cand_finite[(size_t)k * NP + p]) { sel = k; break; }
+        if (a.ws.cand_finite[(size_t)k * NP + p] && isfinite(a.ws.cand_ret[(size_t)k * NP + p])) { sel = k; break; }
     a.ws.sel[p] = sel;
     // no finite alpha: last_return keeps its previous value (-inf on a fresh solver, ilqr.py:87)
     const double r = sel >= 0 ? a.ws.cand_ret[(size_t)sel * NP + p] : a.ws.last_return[p];
@@ -101,7 +110,9 @@ __global__ void pending_kernel(DrvArgs a) {
     if (!a.ws.active[p]) return;
     const double alpha = a.opt.alphas[0];
     const double dret = a.ws.last_return[p] - a.ws.cand_ret[p];
-    const double expected = -1.0 * alpha * (a.ws.dV[p] + alpha * a.ws.dV[NP + p]);
+    double dV0, dV1;
+    load_dV(a, p, NP, dV0, dV1);
+    const double expected = -1.0 * alpha * (dV0 + alpha * dV1);
     if (!(dret / expected >= a.opt.min_imp)) {
         const int j = atomicAdd(a.ws.pending_count, 1);
         a.ws.pending_list[j] = (int32_t)p;
@@ -123,7 +134,8 @@ __device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_
     a.ws.sel[p] = -1;
     if (!a.ws.active[p]) return;
     const double last = a.ws.last_return[p];
-    const double dV0 = a.ws.dV[p], dV1 = a.ws.dV[NP + p];
+    double dV0, dV1;
+    load_dV(a, p, NP, dV0, dV1);
     int sel = -1;
     double best = 0.0, dret_sel = 0.0, alpha_last = a.ws.alpha[p];
     // the first 16 returns are fetched up front: behind the loop's early exit they were one dependent L2 round trip

@@ -80,15 +80,18 @@ template <int K> __device__ __forceinline__ Dual<K> operator/(const Dual<K>& a, 
 // sin and cos together.  fp64 issue slots are what these kernels pay for (one fp64 op per ~5 cycles per SIMD; the
 // library sincos is ~85 of them plus a Payne-Hanek path whose registers and branches sit in the hot loop).
 // Here: 3-term Cody-Waite reduction by pi/2 (k * pio2_1 is exact for |k| < 2^20: 33 + 20 bits) and the fdlibm
-// minimax kernels on |r| <= pi/4: absolute error ~1.5e-16, ~30 instructions.  Arguments beyond 2^20 (only
+// minimax kernels on |r| <= pi/4: absolute error ~1.5e-16, ~30 instructions.  Arguments in [2^20, 1e15) (only
 // rollouts that have already blown up reach them) are first folded by 2 pi with a two-term constant, which
-// costs accuracy proportional to |x| (|x| * 2e-16) but stays finite and bounded; inf / NaN give NaN.
+// costs accuracy proportional to |x| (|x| * 2e-16).  Beyond 1e15 the fold has no correct bits left (and the quadrant
+// conversion below would overflow an int): the result is NaN, as for inf / NaN - the reference's libm sin / cos stay
+// bounded there, so such a candidate's return is a huge finite number for the reference and NaN here; both reject it
+// in the line search (ilqr.py:196 compares false), and init_select_kernel refuses a non-finite return.
 __device__ __forceinline__ void sincos_g(double x, double& s, double& c) {
     const bool big = !(fabs(x) < 1048576.0);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(big) != 0, 0)) {   // one scalar branch for the whole wave
         const double k2 = rint(x * 1.59154943091895345554e-01);        // 1 / (2 pi)
         const double xf = fma(-k2, 2.44929359829470641435e-16, fma(-k2, 6.28318530717958623200e+00, x));
-        x = big ? xf : x;
+        x = big ? (fabs(x) < 1e15 ? xf : __builtin_nan("")) : x;
     }
     const double fk = rint(x * 6.36619772367581382433e-01);
     double r = fma(-fk, 1.57079632673412561417e+00, x);

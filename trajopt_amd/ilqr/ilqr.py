@@ -114,7 +114,8 @@ class BatchedILQR:
         self._Cxx, self._cx = zg(n, n, T + 1), zg(n, T + 1)
         self._Cuu, self._cu, self._Cxu = zg(m, m, T + 1), zg(m, T + 1), zg(n, m, T + 1)
         self._cand_K, self._cand_kff = zg(m, n, T), zg(m, T)
-        self._dV, self._g_norm = z(2, N), z(N)
+        # dV = [kff'qu, 1/2 kff'Quu kff] per problem belongs to the gains group: (2, N) for PROBLEM_MINOR, (N, 2) for MAJOR
+        self._dV, self._g_norm = (z(2, N) if GL == LAYOUT_PROBLEM_MINOR else z(N, 2)), z(N)
         self._diverge, self._active, self._sel = torch.zeros(N, **i32), torch.zeros(N, **i32), torch.zeros(N, **i32)
         self._cand_state, self._cand_action = z(na, T + 1, n, N), z(na, T, m, N)
         self._cand_ret, self._cand_finite = z(na, N), torch.zeros((na, N), **i32)
@@ -138,6 +139,7 @@ class BatchedILQR:
         self._opt = o
         self._ws = self._make_ws()
         self._initialised = False
+        self._trace_bound = 0
         self._lmbda0, self._dlmbda0 = float(lmbda), float(dlmbda)
 
     def reset(self, init_state, kff_init=None):
@@ -158,8 +160,9 @@ class BatchedILQR:
         self.K.zero_()
         if kff_init is None:
             kff_init = 1e-4 * np.random.randn(N, m, T)
-        if torch.is_tensor(kff_init):
-            self.kff.copy_(kff_init.reshape(self.kff.shape))
+        if torch.is_tensor(kff_init):   # logical (N, m, T), as the NumPy branch: permuted into the gains layout
+            k = kff_init.detach().to(device=self.device, dtype=torch.float64).reshape(N, m, T)
+            self.kff.copy_(k.permute(2, 1, 0) if self.gains_layout == LAYOUT_PROBLEM_MINOR else k.permute(0, 2, 1))
         else:
             self.kff.copy_(to_device(np.asarray(kff_init, dtype=np.float64).reshape(N, m, T), self.gains_layout,
                                      self.device))
@@ -170,7 +173,21 @@ class BatchedILQR:
         self.status.zero_()
         self.iters.zero_()
         self.trace_len.zero_()
+        self._trace_bound = 0
         self._initialised = False
+
+    def _reserve_trace(self, nb_iter):
+        """The device appends one return per accepted iteration (ilqr.py:219) and drops what does not fit: make room
+        for `nb_iter` more entries first (upper bound kept on the host, so no synchronisation)."""
+        import torch
+        need = self._trace_bound + int(nb_iter)
+        if need > self.trace_cap:
+            cap = max(need, 2 * self.trace_cap)
+            trace = torch.zeros((cap, self.nb_problems), dtype=torch.float64, device=self.device)
+            trace[:self.trace_cap] = self.trace
+            self.trace, self.trace_cap = trace, cap
+            self._ws = self._make_ws()
+        self._trace_bound = need
 
     def _make_ws(self):
         w = ILQRWorkspace()
@@ -193,10 +210,12 @@ class BatchedILQR:
     def init_rollout(self):
         """ilqr.py:139-149."""
         check(lib().trajopt_ilqr_init_rollout(C.byref(self._struct), C.byref(self._opt), C.byref(self._ws), stream_ptr()))
+        self._trace_bound = 1            # trace[0] = the initial return (ilqr.py:149)
         self._initialised = True
 
     def iterate(self, nb_iter=1):
         """`nb_iter` iterations of ilqr.py:151-231 for every problem still running; asynchronous."""
+        self._reserve_trace(nb_iter)
         check(lib().trajopt_ilqr_iterate(C.byref(self._struct), C.byref(self._opt), C.byref(self._ws), int(nb_iter),
                                          stream_ptr()))
 

@@ -30,14 +30,25 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
 
+def _comm_tensor(t, group=None):
+    """`t` on the device the process group's backend communicates from: RCCL ("nccl") takes GPU tensors as they
+    are, gloo takes host tensors (several ranks may share one GPU in a rehearsal: their results cross on the CPU)."""
+    dist = _dist()
+    if dist is not None and t.is_cuda and dist.get_backend(group) != "nccl":
+        return t.cpu()
+    return t
+
+
 def gather_problem_vector(local, nb_problems, group=None):
     """All ranks receive the full [nb_problems] vector assembled from the per-rank blocks (ragged blocks are
-    padded to the largest one for the all_gather).  `local` is a 1-D torch tensor on the backend's device."""
+    padded to the largest one for the all_gather).  `local` is a 1-D torch tensor; the result lives on the
+    backend's device (the GPU under RCCL, the host under gloo)."""
     import torch
     dist = _dist()
     if dist is None:
         assert local.numel() == nb_problems
         return local.clone()
+    local = _comm_tensor(local, group)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = shard_bounds(nb_problems, world, rank)
     assert local.numel() == hi - lo, "rank %d holds %d problems, expected %d" % (rank, local.numel(), hi - lo)
@@ -57,6 +68,7 @@ def reduce_progress(last_return, status, lmbda, group=None):
     """Global [sum of costs, #stopped (status != 0), #gave up (status == 3), max lambda] over all ranks."""
     import torch
     dist = _dist()
+    last_return, status, lmbda = (_comm_tensor(t, group) for t in (last_return, status, lmbda))
     fin = torch.where(torch.isfinite(last_return), last_return, torch.zeros_like(last_return))
     sums = torch.stack([fin.sum(), (status != 0).sum().to(fin.dtype), (status == 3).sum().to(fin.dtype)])
     mx = lmbda.max().reshape(1).to(fin.dtype) if lmbda.numel() else torch.zeros(1, dtype=fin.dtype, device=fin.device)
