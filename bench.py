@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=500)
     ap.add_argument("--env", default="cartpole")
     ap.add_argument("--staged", type=int, default=-1, help="line search: -1 auto, 0 one launch, 1 staged (same results)")
+    ap.add_argument("--no-fusion", action="store_true", help="quadratise and backward pass as two launches (same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     a = ap.parse_args()
@@ -143,7 +144,8 @@ def main():
     n, m = env.dm_state, env.dm_act
     x0, kff0 = make_problem_set(env, N, T, 1337 + rank)
     solver = BatchedILQR(env, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False,
-                         tolfun=-float("inf"), tolgrad=0.0, max_lmbda=float("inf"), staged_line_search=a.staged)
+                         tolfun=-float("inf"), tolgrad=0.0, max_lmbda=float("inf"), staged_line_search=a.staged, no_fusion=a.no_fusion,
+                         trace_cap=W + K + 16)
     nb_alphas = solver.alphas.size
     L = _lib.lib()
     KERNEL_PHASES = ("quadratize", "backward", "rollout", "select_commit")

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TRAJOPT_ABI_VERSION 3
+#define TRAJOPT_ABI_VERSION 4
 
 #define TRAJOPT_OK 0
 #define TRAJOPT_ERR_BAD_ARG (-1)      /* null pointer, non-positive size, unknown enum            */
@@ -132,7 +132,18 @@ typedef struct trajopt_backward_io {
     const double* cost_w;
     double cost_gxx[TRAJOPT_ENV_MAX_STATE];
     double cost_guu[TRAJOPT_ENV_MAX_ACT];
+    /* Kernel family (ABI v4; per call, so the library keeps no mutable global state): TRAJOPT_KERNEL_AUTO = the
+     * library's choice for the shape, layout and batch size; any other value forces that family (the parity tests
+     * run every family against the oracle) and returns TRAJOPT_ERR_UNSUPPORTED where it has no kernel for the shape. */
+    int32_t kernel;
+    int32_t pad_;
 } trajopt_backward_io_t;
+
+#define TRAJOPT_KERNEL_AUTO 0
+#define TRAJOPT_KERNEL_WORKGROUP 1   /* workgroup = problem, any dx <= 64, du <= 16 (bwd_wg.hip)                    */
+#define TRAJOPT_KERNEL_MFMA16 2      /* wave = problem, fp64 matrix cores, dx + du <= 16, du <= 4 (bwd_mfma16.hip)  */
+#define TRAJOPT_KERNEL_LANE 3        /* lane = problem, PROBLEM_MINOR, dx <= 6 (bwd_tpp.hip)                        */
+#define TRAJOPT_KERNEL_MFMA4 4       /* four problems per wave, PROBLEM_MINOR, dx <= 4, du = 1 (bwd_mfma4.hip)      */
 
 /* 1 when the batched backward pass accepts io->cost_w for this shape, else 0. */
 int trajopt_backward_supports_structured_cost(int dm_state, int dm_act, int nb_steps, int64_t nb_problems, int layout);
@@ -337,7 +348,9 @@ typedef struct trajopt_ilqr_options {
      *       ws->pending_list / ws->pending_count; ignored with argmin_alpha);
      *  -1 = pick by batch size. */
     int32_t staged_line_search;
-    int32_t pad_;
+    /* 1 = never fuse the quadratisation into the backward kernel (fused_qb4.hip): always the two launches
+     * quadratise -> backward pass.  Same results to round-off; for tests and measurements. */
+    int32_t no_fusion;
 } trajopt_ilqr_options_t;
 
 typedef struct trajopt_ilqr_workspace {
@@ -385,6 +398,17 @@ int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_optio
  * rollout over all alphas -> first-accept selection -> accept/reject and lambda update. */
 int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
                          const trajopt_ilqr_workspace_t* ws, int nb_iter, void* stream);
+
+/* What trajopt_ilqr_iterate will launch for this env / options / workspace (no counterpart in the reference; used by
+ * bench.py to attribute bytes and flops to the kernels that actually run). */
+typedef struct trajopt_ilqr_plan {
+    int32_t structured_cost;   /* 1: closed-form Cxx / Cuu / Cxu formed inside the backward kernel (cost_w)            */
+    int32_t fused_quad_bwd;    /* 1: quadratisation and backward pass are one launch (fused_qb4.hip)                   */
+    int32_t staged_line_search;/* 1: alphas[0] for everybody, the rest for the compacted list of rejecting problems   */
+    int32_t backward_kernel;   /* TRAJOPT_KERNEL_* family of the backward pass                                         */
+} trajopt_ilqr_plan_t;
+int trajopt_ilqr_plan(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt, const trajopt_ilqr_workspace_t* ws,
+                      trajopt_ilqr_plan_t* plan);
 
 /* Per-phase device timing of trajopt_ilqr_iterate (measurement aid; no counterpart in the reference, which
  * has no timers).  begin() creates hipEvents for up to `max_iterations` iterations; while enabled, iterate

@@ -40,14 +40,9 @@ def main():
     ap.add_argument("--n", type=int, default=4); ap.add_argument("--m", type=int, default=1)
     ap.add_argument("--T", type=int, default=500); ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--layout", type=int, default=1); ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--same-step", type=int, default=0); ap.add_argument("--lpw", type=int, default=0)
-    ap.add_argument("--force-wg", type=int, default=0)
+    ap.add_argument("--kernel", type=int, default=0, help="trajopt_backward_io_t::kernel (0 = the library's choice)")
     a = ap.parse_args()
     n, m, T, N = a.n, a.m, a.T, a.N
-    from trajopt_amd._lib import lib
-    lib().trajopt_debug_tpp_same_step(a.same_step)
-    lib().trajopt_debug_tpp_lpw(a.lpw)
-    lib().trajopt_debug_force_kernel(a.force_wg)
     d = make(n, m, T, N, a.layout, a.variant == "riccati")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if a.variant == "riccati":
@@ -71,12 +66,12 @@ def main():
         out = {}
         for _ in range(2):
             backward.ilqr_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"], lam, 1, n, m, T,
-                                        N, a.layout, full=full, out=out)
+                                        N, a.layout, full=full, out=out, kernel=a.kernel)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(a.reps):
             backward.ilqr_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"], lam, 1, n, m, T,
-                                        N, a.layout, full=full, out=out)
+                                        N, a.layout, full=full, out=out, kernel=a.kernel)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.reps
         b = 8 * (4 * n * n + 4 * n * m + 2 * m * m + 3 * n + 3 * m) if full else \

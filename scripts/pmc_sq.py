@@ -1,0 +1,43 @@
+"""Reduce a rocprofv3 --pmc pass of SQ / GRBM counters to per-kernel means per launch.
+
+  python scripts/pmc_sq.py <counter_collection.csv> <out.json> "workload text"
+
+Counters (one pass: 8 SQ + 1 GRBM): SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES
+SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE (MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* /
+SQ_ACTIVE_INST_* count quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def main():
+    path, out, workload = sys.argv[1:4]
+    tot, cnt = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            k = row["Kernel_Name"].replace("void ", "").split("(")[0]
+            if "trajopt::" not in k:
+                continue
+            c = row["Counter_Name"]
+            tot[k][c] += float(row["Counter_Value"])
+            cnt[k][c] += 1
+    res = {}
+    for k in sorted(tot):
+        d = {c: tot[k][c] / cnt[k][c] for c in tot[k]}
+        d["launches"] = max(cnt[k].values())
+        if d.get("SQ_WAVES") and d.get("SQ_INSTS_VALU"):
+            d["valu_insts_per_wave"] = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
+        if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_INSTS_VALU"):
+            cyc = d["GRBM_GUI_ACTIVE"] / 8.0          # shader-clock cycles the launch was busy (per XCD)
+            d["gpu_cycles"] = cyc
+            d["valu_insts_per_simd_cycle"] = d["SQ_INSTS_VALU"] / (cyc * 1024.0)
+        res[k] = d
+    json.dump({"workload": workload, "units": "means per launch; SQ_* summed over all SIMDs/XCDs", "kernels": res},
+              open(out, "w"), indent=1)
+    for k, d in res.items():
+        print(k, json.dumps({c: round(v, 3) for c, v in d.items()}))
+
+
+if __name__ == "__main__":
+    main()

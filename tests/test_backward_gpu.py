@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 OUT = ("Qxx", "Qux", "Quu", "qx", "qu", "V", "v", "dV", "K", "kff")
 
 
-def _run_gpu(stack, lmbda, reg, n, m, T, N, layout, full=True, retry=False, sched=None, uref=None):
+def _run_gpu(stack, lmbda, reg, n, m, T, N, layout, full=True, retry=False, sched=None, uref=None, kernel=0):
     import torch
     from trajopt_amd import backward, layout as L
     d = {k: L.to_device(v, layout) for k, v in stack.items()}
@@ -20,7 +20,7 @@ def _run_gpu(stack, lmbda, reg, n, m, T, N, layout, full=True, retry=False, sche
     dl = torch.ones(N, dtype=torch.float64, device="cuda") if retry else None
     u = L.to_device(uref, layout) if uref is not None else None
     o = backward.ilqr_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"], lam, reg, n, m, T,
-                                    N, layout, full=full, retry=retry, sched=sched, dlmbda=dl, uref=u)
+                                    N, layout, full=full, retry=retry, sched=sched, dlmbda=dl, uref=u, kernel=kernel)
     torch.cuda.synchronize()
     res = {k: L.from_device(o[k], layout) for k in o if k not in ("diverge", "g_norm")}
     res["diverge"] = o["diverge"].cpu().numpy()
@@ -49,13 +49,8 @@ def test_ilqr_backward_matches_oracle(oracle, n, m, T, N, layout, reg):
             assert_close(res[k][p], r, "%s[p=%d]" % (k, p))
 
 
-@pytest.fixture
-def force_kernel():
-    """Route the batched entry to one kernel family: 1 workgroup-per-problem, 2 MFMA wave-per-problem,
-    3 lane-per-problem, 4 MFMA four-problems-per-wave (0 = the library's own choice)."""
-    from trajopt_amd._lib import lib
-    yield lambda which: lib().trajopt_debug_force_kernel(int(which))
-    lib().trajopt_debug_force_kernel(0)
+# kernel families (trajopt_backward_io_t::kernel, include/trajopt_amd.h): 1 workgroup-per-problem, 2 MFMA
+# wave-per-problem, 3 lane-per-problem, 4 MFMA four-problems-per-wave (0 = the library's own choice)
 
 
 @pytest.mark.parametrize("kernel,n,m,T,N,layout", [
@@ -68,12 +63,11 @@ def force_kernel():
     (4, 4, 1, 500, 37, 1),
 ])
 @pytest.mark.parametrize("reg", [1, 2])
-def test_every_kernel_family_matches_oracle(oracle, force_kernel, kernel, n, m, T, N, layout, reg):
+def test_every_kernel_family_matches_oracle(oracle, kernel, n, m, T, N, layout, reg):
     from trajopt_amd import synthetic as S
-    force_kernel(kernel)
     stack = S.backward_inputs(n, m, T, N, seed=4000 + 10 * n + m)
     uref = np.random.default_rng(n).standard_normal((N, m, T))
-    res = _run_gpu(stack, 0.8, reg, n, m, T, N, layout, uref=uref)
+    res = _run_gpu(stack, 0.8, reg, n, m, T, N, layout, uref=uref, kernel=kernel)
     for p in range(N):
         q = S.problem(stack, p)
         ref, failed = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], 0.8, reg, n,
@@ -86,16 +80,15 @@ def test_every_kernel_family_matches_oracle(oracle, force_kernel, kernel, n, m, 
 
 
 @pytest.mark.parametrize("kernel,n,m", [(1, 6, 2), (2, 6, 2), (3, 4, 1), (4, 4, 1), (4, 3, 1)])
-def test_asymmetric_cost_hessians_are_taken_as_given(oracle, force_kernel, kernel, n, m):
+def test_asymmetric_cost_hessians_are_taken_as_given(oracle, kernel, n, m):
     """util.cpp uses Cxx as passed (no symmetry assumed); only V is symmetrised (:161)."""
     from trajopt_amd import synthetic as S
     T, N = 10, 3
-    force_kernel(kernel)
     stack = S.backward_inputs(n, m, T, N, seed=99)
     Cxx = np.array(stack["Cxx"])
     Cxx[:, 0, 1, :] += 0.05          # asymmetric, terminal slice included
     stack = dict(stack, Cxx=Cxx)
-    res = _run_gpu(stack, 1.0, 1, n, m, T, N, 1 if kernel >= 3 else 0)
+    res = _run_gpu(stack, 1.0, 1, n, m, T, N, 1 if kernel >= 3 else 0, kernel=kernel)
     for p in range(N):
         q = S.problem(stack, p)
         ref, _ = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], 1.0, 1, n, m, T)
@@ -244,14 +237,13 @@ def test_riccati_backward_matches_oracle(oracle, n, m, T, N, layout):
 @pytest.mark.parametrize("kernel", [0, 3, 4])
 @pytest.mark.parametrize("n,m,T,N", [(4, 1, 64, 130), (2, 1, 33, 5), (3, 1, 20, 17), (6, 1, 30, 70), (4, 2, 25, 66)])
 @pytest.mark.parametrize("reg", [1, 2])
-def test_structured_cost_matches_dense_oracle(oracle, force_kernel, kernel, n, m, T, N, reg):
+def test_structured_cost_matches_dense_oracle(oracle, kernel, n, m, T, N, reg):
     """trajopt_backward_io_t::cost_w: Cxx = w[t] diag(gxx), Cuu = diag(guu), Cxu = 0 formed inside the kernel give
     what the oracle gives on the equivalent dense arrays (both kernel families that implement it)."""
     import torch
     from trajopt_amd import backward, layout as L, synthetic as S
     if kernel == 4 and not (m == 1 and n <= 4):
         pytest.skip("the four-problems-per-wave kernel covers dm_state <= 4, dm_act = 1")
-    force_kernel(kernel)
     rng = np.random.default_rng(100 * n + m)
     stack = S.backward_inputs(n, m, T, N, seed=900 + n)
     w = np.abs(rng.standard_normal(T + 1)) + 0.1
@@ -265,7 +257,7 @@ def test_structured_cost_matches_dense_oracle(oracle, force_kernel, kernel, n, m
     uref = rng.standard_normal((N, m, T))
     lam = torch.full((N,), 0.7, dtype=torch.float64, device="cuda")
     o = backward.ilqr_backward_pass(None, d["cx"], None, d["cu"], None, d["A"], d["B"], lam, reg, n, m, T, N, 1,
-                                    uref=L.to_device(uref, 1),
+                                    uref=L.to_device(uref, 1), kernel=kernel,
                                     cost=(torch.as_tensor(w, device="cuda"), gxx, guu))
     torch.cuda.synchronize()
     assert not (o["diverge"].cpu().numpy() >= 0).any()
@@ -294,3 +286,19 @@ def test_structured_cost_is_refused_where_no_kernel_takes_it():
     with pytest.raises(TrajoptError):
         backward.ilqr_backward_pass(None, d["cx"], None, d["cu"], None, d["A"], d["B"], lam, 1, n, m, T, N, 1,
                                     cost=(torch.ones(T + 1, dtype=torch.float64, device="cuda"), np.ones(n), np.ones(m)))
+
+
+def test_a_forced_kernel_family_without_the_shape_is_refused():
+    """trajopt_backward_io_t::kernel names a family per call (no global state): where that family has no kernel for
+    the shape or layout the call fails with TRAJOPT_ERR_UNSUPPORTED instead of silently taking another one."""
+    import torch
+    from trajopt_amd import backward, layout as L, synthetic as S
+    from trajopt_amd._lib import TrajoptError
+    n, m, T, N = 6, 2, 8, 3
+    stack = S.backward_inputs(n, m, T, N, seed=1)
+    for kernel, layout in ((4, 1), (3, 1), (3, 0), (7, 1)):
+        d = {k: L.to_device(v, layout) for k, v in stack.items()}
+        lam = torch.ones(N, dtype=torch.float64, device="cuda")
+        with pytest.raises(TrajoptError):
+            backward.ilqr_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"], lam, 1, n, m, T,
+                                        N, layout, kernel=kernel)

@@ -13,7 +13,7 @@ SO_PATH = os.path.join(_HERE, "libtrajopt_amd.so")
 LAYOUT_PROBLEM_MAJOR = 0
 LAYOUT_PROBLEM_MINOR = 1
 MAX_ALPHAS = 16
-ABI_VERSION = 3          # include/trajopt_amd.h::TRAJOPT_ABI_VERSION
+ABI_VERSION = 4          # include/trajopt_amd.h::TRAJOPT_ABI_VERSION
 MAX_STATE, MAX_ACT = 12, 4
 
 ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR, ENV_DOUBLE_PENDULUM, ENV_ROBOT, ENV_QUAD_PENDULUM = 1, 2, 3, 4, 5, 6, 7, 8
@@ -51,7 +51,8 @@ class BackwardIO(C.Structure):
                  ("Cxx", "cx", "Cuu", "cu", "Cxu", "A", "B", "lmbda", "dlmbda",
                   "Qxx", "Qux", "Quu", "qx", "qu", "V", "v", "dV", "K", "kff", "diverge",
                   "uref", "g_norm", "active", "cost_w")] +
-                [("cost_gxx", C.c_double * MAX_STATE), ("cost_guu", C.c_double * MAX_ACT)])
+                [("cost_gxx", C.c_double * MAX_STATE), ("cost_guu", C.c_double * MAX_ACT),
+                 ("kernel", C.c_int32), ("pad_", C.c_int32)])
 
 
 class GpsBackwardIO(C.Structure):
@@ -72,7 +73,16 @@ class ILQROptions(C.Structure):
     _fields_ = [("sched", LambdaSchedule), ("tolfun", C.c_double), ("tolgrad", C.c_double),
                 ("min_imp", C.c_double), ("reg", C.c_int32), ("nb_alphas", C.c_int32),
                 ("alphas", C.c_double * MAX_ALPHAS), ("argmin_alpha", C.c_int32), ("keep_value", C.c_int32),
-                ("staged_line_search", C.c_int32), ("pad_", C.c_int32)]
+                ("staged_line_search", C.c_int32), ("no_fusion", C.c_int32)]
+
+
+class ILQRPlan(C.Structure):
+    """include/trajopt_amd.h::trajopt_ilqr_plan_t"""
+    _fields_ = [("structured_cost", C.c_int32), ("fused_quad_bwd", C.c_int32), ("staged_line_search", C.c_int32),
+                ("backward_kernel", C.c_int32)]
+
+
+KERNEL_AUTO, KERNEL_WORKGROUP, KERNEL_MFMA16, KERNEL_LANE, KERNEL_MFMA4 = 0, 1, 2, 3, 4
 
 
 class ILQRWorkspace(C.Structure):
@@ -100,7 +110,7 @@ EXPORTS = (
     "trajopt_bspilqr_backward_supported", "trajopt_bspilqr_backward_pass_batched", "trajopt_bspilqr_backward_pass_host",
     "trajopt_riccati_backward_pass_host", "trajopt_riccati_backward_pass_batched",
     "trajopt_env_step_batched", "trajopt_ilqr_forward_pass_batched", "trajopt_quadratize_batched",
-    "trajopt_ilqr_init_rollout", "trajopt_ilqr_iterate", "trajopt_convert_layout",
+    "trajopt_ilqr_init_rollout", "trajopt_ilqr_iterate", "trajopt_ilqr_plan", "trajopt_convert_layout",
     "trajopt_profile_begin", "trajopt_profile_end", "trajopt_profile_select",
 )
 

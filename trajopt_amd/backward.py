@@ -16,7 +16,8 @@ def _chk(t, numel, name):
 
 
 def ilqr_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, dm_state, dm_act, nb_steps, nb_problems, layout,
-                       full=True, retry=False, sched=None, dlmbda=None, uref=None, active=None, out=None, cost=None):
+                       full=True, retry=False, sched=None, dlmbda=None, uref=None, active=None, out=None, cost=None,
+                       kernel=0):
     """Regularised Riccati recursion of /root/reference/trajopt/ilqr/src/util.cpp:83-182 for a batch.
 
     Inputs are device tensors in `layout` (see layout.py); `lmbda` is a [N] tensor (updated in place when
@@ -24,6 +25,7 @@ def ilqr_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, dm_state, dm_act
     g_norm when uref is given).  diverge[p] = -1 when every step passed the PD test.
     cost=(w, gxx, guu): structured cost (trajopt_backward_io_t::cost_w) - Cxx[t] = w[t] diag(gxx), Cuu = diag(guu),
     Cxu = 0 for every problem, w a [T+1] device tensor; Cxx, Cuu, Cxu are then ignored and may be None.
+    kernel: _lib.KERNEL_* family (0 = the library's choice; the parity tests force each family in turn).
     """
     import torch
     _lib.require_gpu()
@@ -69,6 +71,7 @@ def ilqr_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, dm_state, dm_act
         setattr(io, k, dptr(o.get(k)) if full else None)
     io.dV, io.K, io.kff, io.diverge = dptr(o["dV"]), dptr(o["K"]), dptr(o["kff"]), dptr(o["diverge"])
     io.uref, io.g_norm, io.active = dptr(uref), dptr(o.get("g_norm")), dptr(active)
+    io.kernel = int(kernel)
     s = sched if sched is not None else LambdaSchedule(1e-6, 1e6, 1.6)
     check(lib().trajopt_ilqr_backward_pass_batched(C.byref(io), int(reg), n, m, T, C.c_int64(N), int(layout),
                                                    int(bool(retry)), C.byref(s), stream_ptr()))

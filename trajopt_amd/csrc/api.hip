@@ -15,10 +15,6 @@ void set_hip_error(hipError_t e, const char* where) {
     snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
 }
 
-extern int g_tpp_dbg_same_step;
-extern int g_tpp_lpw;
-// tests / benches: 0 auto, 1 workgroup-per-problem, 2 MFMA wave-per-problem, 3 lane-per-problem, 4 MFMA 4 problems per wave
-static int g_force_kernel = 0;
 
 template <bool TO_MINOR>
 __global__ void convert_layout_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t E, size_t NP) {
@@ -53,6 +49,36 @@ static bool tpp_offsets_fit(int n, int64_t NP) { return (double)n * n * (double)
 
 }  // namespace trajopt
 
+namespace trajopt {
+
+// Kernel family of the regularised backward pass for a shape (TRAJOPT_KERNEL_*), or -1 when `want` names a family
+// without a kernel for it.  want = TRAJOPT_KERNEL_AUTO:  four problems per wave for small struct-of-arrays batches of
+// dx <= 4, du = 1  ->  lane = problem for the struct-of-arrays layout and dx <= 6 (NP == 1: the two layouts are the
+// same memory)  ->  wave = problem on the fp64 matrix cores (dx + du <= 16, du <= 4; best with PROBLEM_MAJOR, whose
+// per-step slices are contiguous)  ->  workgroup = problem.
+int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want) {
+    const bool minor = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR || NP == 1;
+    const bool mfma4_ok = minor && m == 1 && n >= 2 && n <= 4 && (double)(T + 2) * n * n * (double)NP * 8.0 < 4294967296.0;
+    const bool lane_ok = minor && tpp_offsets_fit(n, NP) &&
+                         ((m == 1 && (n == 2 || n == 3 || n == 4 || n == 6)) || (n == 4 && m == 2));
+    const bool mfma16_ok = n + m <= 16 && m <= 4 && n >= 1;
+    const bool wg_ok = n <= 64 && m <= 16;
+    switch (want) {
+        case TRAJOPT_KERNEL_AUTO:
+            if (mfma4_ok && NP <= kMfma4MaxProblems) return TRAJOPT_KERNEL_MFMA4;
+            if (lane_ok) return TRAJOPT_KERNEL_LANE;
+            if (mfma16_ok) return TRAJOPT_KERNEL_MFMA16;
+            return wg_ok ? TRAJOPT_KERNEL_WORKGROUP : -1;
+        case TRAJOPT_KERNEL_MFMA4: return mfma4_ok ? want : -1;
+        case TRAJOPT_KERNEL_LANE: return lane_ok ? want : -1;
+        case TRAJOPT_KERNEL_MFMA16: return mfma16_ok ? want : -1;
+        case TRAJOPT_KERNEL_WORKGROUP: return wg_ok ? want : -1;
+        default: return -1;
+    }
+}
+
+}  // namespace trajopt
+
 using namespace trajopt;
 
 extern "C" {
@@ -79,21 +105,6 @@ int trajopt_device_count(void) {
     return n;
 }
 
-int trajopt_debug_force_kernel(int which) {
-    g_force_kernel = which;
-    return TRAJOPT_OK;
-}
-
-int trajopt_debug_tpp_lpw(int lpw) {
-    g_tpp_lpw = lpw;
-    return TRAJOPT_OK;
-}
-
-int trajopt_debug_tpp_same_step(int on) {
-    g_tpp_dbg_same_step = on;
-    return TRAJOPT_OK;
-}
-
 int trajopt_backward_supports_structured_cost(int n, int m, int T, int64_t NP, int layout) {
     // exactly the shapes the lane-per-problem and the four-problems-per-wave kernels take (see the dispatcher below)
     if (n <= 0 || m <= 0 || T <= 0 || NP <= 0) return 0;
@@ -113,27 +124,18 @@ int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg,
     if (retry && !sched) return TRAJOPT_ERR_BAD_ARG;
     trajopt_lambda_schedule_t s = sched ? *sched : trajopt_lambda_schedule_t{1e-6, 1e6, 1.6};
     hipStream_t st = as_stream(stream);
-    // Kernel choice:  lane = problem for the struct-of-arrays layout and dx <= 6 (NP == 1: the two layouts are the
-    // same memory)  ->  wave = problem on the fp64 matrix cores (dx + du <= 16, du <= 4; best with PROBLEM_MAJOR,
-    // whose per-step slices are contiguous)  ->  workgroup = problem.
-    const bool minor = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR || NP == 1;
-    if (minor && (g_force_kernel == 4 || (g_force_kernel == 0 && NP <= kMfma4MaxProblems))) {
-        bool handled = false;
-        const int rc = launch_backward_mfma4(*io, reg, n, m, T, NP, retry, s, st, &handled);
-        if (rc != TRAJOPT_OK || handled) return rc;
+    const int fam = backward_kernel_family(n, m, T, NP, layout, io->kernel);
+    if (fam < 0 || (io->cost_w && fam != TRAJOPT_KERNEL_LANE && fam != TRAJOPT_KERNEL_MFMA4)) return TRAJOPT_ERR_UNSUPPORTED;
+    bool handled = false;
+    int rc = TRAJOPT_OK;
+    switch (fam) {
+        case TRAJOPT_KERNEL_MFMA4: rc = launch_backward_mfma4(*io, reg, n, m, T, NP, retry, s, st, &handled); break;
+        case TRAJOPT_KERNEL_LANE: rc = launch_backward_tpp(*io, reg, n, m, T, NP, retry, s, st, &handled); break;
+        case TRAJOPT_KERNEL_MFMA16: rc = launch_backward_mfma16(*io, reg, n, m, T, NP, layout, retry, s, st, &handled); break;
+        default: break;
     }
-    const bool tpp_ok = minor && tpp_offsets_fit(n, NP);
-    if (tpp_ok && (g_force_kernel == 3 || g_force_kernel == 0)) {
-        bool handled = false;
-        const int rc = launch_backward_tpp(*io, reg, n, m, T, NP, retry, s, st, &handled);
-        if (rc != TRAJOPT_OK || handled) return rc;
-    }
-    if (io->cost_w) return TRAJOPT_ERR_UNSUPPORTED;  // (a forced kernel family without the structured-cost path)
-    if (g_force_kernel == 0 || g_force_kernel == 2) {
-        bool handled = false;
-        const int rc = launch_backward_mfma16(*io, reg, n, m, T, NP, layout, retry, s, st, &handled);
-        if (rc != TRAJOPT_OK || handled) return rc;
-    }
+    if (rc != TRAJOPT_OK || handled) return rc;
+    if (fam != TRAJOPT_KERNEL_WORKGROUP) return TRAJOPT_ERR_UNSUPPORTED;  // (the family table and a launcher disagree)
     return launch_backward_wg(*io, reg, n, m, T, NP, layout, retry, s, st);
 }
 
@@ -144,7 +146,7 @@ int trajopt_riccati_backward_pass_batched(const double* Cxx, const double* cx, c
     if (!Cxx || !cx || !Cuu || !cu || !Cxu || !A || !B || !c || !V || !v || !K || !kff) return TRAJOPT_ERR_BAD_ARG;
     if (n <= 0 || m <= 0 || T <= 0 || NP <= 0) return TRAJOPT_ERR_BAD_ARG;
     if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
-    if (g_force_kernel == 0 || g_force_kernel == 2) {  // tiled matrix-core kernel (16 < dx <= 64, PROBLEM_MAJOR)
+    {  // tiled matrix-core kernel (16 < dx <= 64, PROBLEM_MAJOR)
         bool handled = false;
         const int rc = launch_riccati_mfma64(Cxx, cx, Cuu, cu, Cxu, A, B, c, n, m, T, NP, layout, V, v, K, kff, status,
                                              as_stream(stream), &handled);

@@ -37,14 +37,11 @@
 
 namespace trajopt {
 
-extern int g_tpp_dbg_same_step;
-
 struct M4Args {
     trajopt_backward_io_t io;
     trajopt_lambda_schedule_t sched;
     size_t NP;
     int T, reg, retry;
-    int dbg_same_step;  // developer knob: load step T-1 every step (cache-resident inputs) to time the arithmetic
 };
 
 __device__ __forceinline__ double m4_mm(double a, double b, double c) {
@@ -288,7 +285,8 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
             for (int k = 0; k < kRing; ++k) {
                 step(ring[k], t);
                 m4_load<N, SC>(ring[k], io, ol, pl, in_rc, p_live);
-                if (!a.dbg_same_step) { back(ol); pl -= p_stride; }
+                back(ol);
+                pl -= p_stride;
                 --t;
             }
         }
@@ -371,7 +369,6 @@ int launch_backward_mfma4(const trajopt_backward_io_t& io, int reg, int n, int m
     if ((double)(T + 2) * n * n * (double)NP * 8.0 >= 4294967296.0) return TRAJOPT_OK;
     M4Args a;
     a.io = io; a.sched = sched; a.NP = (size_t)NP; a.T = T; a.reg = reg; a.retry = retry;
-    a.dbg_same_step = g_tpp_dbg_same_step;
     *handled = true;
     if (n == 2) return m4_launch_n<2>(a, st);
     if (n == 3) return m4_launch_n<3>(a, st);

@@ -23,7 +23,6 @@ struct TppArgs {
     size_t NP;
     int T, reg, retry;
     int lpw;            // problems (active lanes) per wave: 64 for big batches, fewer to spread a small batch over all CUs
-    int dbg_same_step;  // developer knob: reload step T-1 every step (cache-resident inputs) to time the arithmetic
 };
 
 // Addressing: every access is a raw buffer load/store
@@ -65,7 +64,6 @@ __device__ __forceinline__ void store_vec(double* ubase, const Lane& ln, const d
 template <int N, int M, bool GN, bool SC>
 __device__ __forceinline__ void load_step(StepIn<N, M>& s, const TppArgs& a, size_t p0, const Lane& off, int t) {
     const size_t NP = a.NP;
-    if (a.dbg_same_step) t = a.T - 1;
     load_vec<N * N>(s.A, UBASE(a.io.A, N * N, t), off);
     load_vec<N * M>(s.B, UBASE(a.io.B, N * M, t), off);
     if constexpr (SC) {
@@ -397,14 +395,11 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
     }
 }
 
-int g_tpp_dbg_same_step = 0;
-int g_tpp_lpw = 0;  // developer knob: force the problems-per-wave choice (0 = automatic)
 
 // Problems per wave.  Measured on MI355X (C2, 4096 cartpoles, gains-only): 64 lanes 0.56 ms, 32 / 16 lanes
 // 0.67 ms, 8 lanes 0.9 ms - a wave's step costs the same ~350 fp64 issue slots whatever its active lanes and
 // more, emptier waves only add contention, so full waves win even when they cover a quarter of the CUs.
 static int pick_lpw(size_t) {
-    if (g_tpp_lpw == 8 || g_tpp_lpw == 16 || g_tpp_lpw == 32 || g_tpp_lpw == 64) return g_tpp_lpw;
     return 64;
 }
 
@@ -438,7 +433,6 @@ int launch_backward_tpp(const trajopt_backward_io_t& io, int reg, int n, int m, 
     a.T = T;
     a.reg = reg;
     a.retry = retry;
-    a.dbg_same_step = g_tpp_dbg_same_step;
     a.lpw = pick_lpw(a.NP);
     *handled = true;
     if (n == 2 && m == 1) return launch_nm<2, 1>(a, st);

@@ -39,6 +39,15 @@ __device__ __forceinline__ double rcp_nr(double x) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Fused commit of the previous iteration's line search (driver only; ilqr.py:210-217): where sel[p] >= 0 the reference
+// trajectory is read from candidate plane sel[p] and written through to xref / uref, and the candidate gains are promoted
+// to K / kff.  Used by the quadratisation kernel and by the fused quadratise + backward kernel.
+struct QuadCommit {
+    const int32_t* sel;
+    const double *cand_state, *cand_action, *cand_K, *cand_kff;
+    double *xref, *uref, *K, *kff;
+};
+
 // Kernel launchers implemented per translation unit (all return TRAJOPT_* codes).
 int launch_backward_tpp(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int retry,
                         const trajopt_lambda_schedule_t& sched, hipStream_t st, bool* handled);

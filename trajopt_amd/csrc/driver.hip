@@ -16,15 +16,16 @@ int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, cons
                    const double* alphas_host, int nb_alphas, const int32_t* active, double* state, double* action,
                    double* cost, double* ret, int32_t* finite, hipStream_t st, int k_layout, int alpha_begin,
                    int alpha_end, const int32_t* plist, const int32_t* pcount);
-struct QuadCommit {  // fused commit of the previous line search inside the quadratisation (quadratize.hip)
-    const int32_t* sel;
-    const double *cand_state, *cand_action, *cand_K, *cand_kff;
-    double *xref, *uref, *K, *kff;
-};
 int launch_quadratize(const trajopt_env_t* env, int T, int64_t NP, int layout, int convention, const double* xref,
                       const double* uref, const double* weighting, const int32_t* active, double* A, double* B,
                       double* c, double* Cxx, double* cx, double* Cuu, double* cu, double* Cxu, hipStream_t st,
                       const QuadCommit* cm, int out_layout);
+
+bool fused_qb4_supported(const trajopt_env_t* env, int T, int64_t NP);
+int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want);
+int launch_fused_qb4(const trajopt_env_t* env, const trajopt_backward_io_t& io, int reg, int T, int64_t NP, int retry,
+                     const trajopt_lambda_schedule_t& sched, const double* xref, const double* uref,
+                     const QuadCommit* cm, hipStream_t st);
 
 struct DrvArgs {
     trajopt_ilqr_options_t opt;
@@ -321,6 +322,23 @@ int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_optio
     return TRAJOPT_OK;
 }
 
+int trajopt_ilqr_plan(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt, const trajopt_ilqr_workspace_t* ws,
+                      trajopt_ilqr_plan_t* plan) {
+    if (!plan) return TRAJOPT_ERR_BAD_ARG;
+    const int rc = check_ws(env, opt, ws);
+    if (rc != TRAJOPT_OK) return rc;
+    const int n = env->dm_state, m = env->dm_act, T = ws->nb_steps, GL = ws->gains_layout;
+    const int64_t NP = ws->nb_problems;
+    const bool gminor = GL == TRAJOPT_LAYOUT_PROBLEM_MINOR;
+    plan->structured_cost = env->nb_features == 0 && trajopt_backward_supports_structured_cost(n, m, T, NP, GL) != 0;
+    plan->fused_quad_bwd = plan->structured_cost && gminor && !opt->keep_value && !opt->no_fusion && fused_qb4_supported(env, T, NP);
+    bool staged = opt->staged_line_search == 1 || (opt->staged_line_search < 0 && (int64_t)NP * opt->nb_alphas >= 16 * 65536);
+    if (opt->argmin_alpha || opt->nb_alphas < 2 || !ws->pending_list || !ws->pending_count) staged = false;
+    plan->staged_line_search = staged;
+    plan->backward_kernel = plan->fused_quad_bwd ? TRAJOPT_KERNEL_MFMA4 : backward_kernel_family(n, m, T, NP, GL, TRAJOPT_KERNEL_AUTO);
+    return TRAJOPT_OK;
+}
+
 int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
                          const trajopt_ilqr_workspace_t* ws, int nb_iter, void* stream) {
     int rc = check_ws(env, opt, ws);
@@ -354,6 +372,7 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         for (int j = 0; j < m; ++j) io.cost_guu[j] = sc * 2.0 * env->uw[j];
     }
     const bool fuse_commit = !opt->keep_value;
+    const bool fused_qb = structured && gminor && !opt->keep_value && !opt->no_fusion && fused_qb4_supported(env, T, NP);
     // staged line search: worth its second 500-step latency chain, and the scattered accesses of its compacted second
     // stage, only once the one-launch form oversubscribes the chip (1024 SIMDs x 64 lanes) many times over - measured
     // on 65 536 cartpoles x 11 alphas early in an optimisation (most problems reject alphas[0]): one launch 8.6 ms,
@@ -371,14 +390,22 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         // The accepted candidate of iteration it-1 is promoted to xref/uref/K/kff by this iteration's
         // quadratisation (it reads every (problem, step) of the trajectory anyway); only the last iteration
         // of the call, and the keep_value mode, use the stand-alone commit kernel.
-        rc = launch_quadratize(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 0, ws->xref, ws->uref, ws->weighting,
-                               ws->active, ws->A, ws->B, nullptr, structured ? nullptr : ws->Cxx, ws->cx,
-                               structured ? nullptr : ws->Cuu, ws->cu, structured ? nullptr : ws->Cxu, st,
-                               (fuse_commit && it > 0) ? &cm : nullptr, GL);
-        if (rc != TRAJOPT_OK) return rc;
-        prof_mark(st, slot, 2);
-        rc = trajopt_ilqr_backward_pass_batched(&io, opt->reg, n, m, T, NP, GL, 1, &opt->sched, st);
-        if (rc != TRAJOPT_OK) return rc;
+        const QuadCommit* cmp = (fuse_commit && it > 0) ? &cm : nullptr;
+        if (fused_qb) {
+            // small batches of dx <= 4, du = 1 models: quadratisation and recursion in one launch, the expansion
+            // handed over through LDS (fused_qb4.hip); reported under the "backward" phase
+            prof_mark(st, slot, 2);
+            rc = launch_fused_qb4(env, io, opt->reg, T, NP, 1, opt->sched, ws->xref, ws->uref, cmp, st);
+            if (rc != TRAJOPT_OK) return rc;
+        } else {
+            rc = launch_quadratize(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 0, ws->xref, ws->uref, ws->weighting,
+                                   ws->active, ws->A, ws->B, nullptr, structured ? nullptr : ws->Cxx, ws->cx,
+                                   structured ? nullptr : ws->Cuu, ws->cu, structured ? nullptr : ws->Cxu, st, cmp, GL);
+            if (rc != TRAJOPT_OK) return rc;
+            prof_mark(st, slot, 2);
+            rc = trajopt_ilqr_backward_pass_batched(&io, opt->reg, n, m, T, NP, GL, 1, &opt->sched, st);
+            if (rc != TRAJOPT_OK) return rc;
+        }
         if (!gminor) hipLaunchKernelGGL(gnorm_major_kernel, dim3((unsigned)NP), dim3(64), 0, st, a);
         prof_mark(st, slot, 3);
         hipLaunchKernelGGL(post_backward_kernel, dim3(g1), dim3(256), 0, st, a);

@@ -15,11 +15,6 @@
 
 namespace trajopt {
 
-struct QuadCommit {  // see QuadArgs::sel
-    const int32_t* sel;
-    const double *cand_state, *cand_action, *cand_K, *cand_kff;
-    double *xref, *uref, *K, *kff;
-};
 
 struct QuadArgs {
     trajopt_env_t env;

@@ -58,7 +58,7 @@ class BatchedILQR:
                  action_penalty=False, alphas=DEFAULT_ALPHAS, lmbda=1., dlmbda=1., min_lmbda=1e-6, max_lmbda=1e6,
                  mult_lmbda=1.6, tolfun=1e-6, tolgrad=1e-4, min_imp=0., reg=1, argmin_alpha=False,
                  keep_value=False, trace_cap=None, device=None, apply_env_kwargs=True, gains_layout=None,
-                 staged_line_search=-1):
+                 staged_line_search=-1, no_fusion=False):
         import torch
         _lib.require_gpu()
         self.env = env
@@ -136,6 +136,7 @@ class BatchedILQR:
             o.alphas[i] = float(a)
         o.argmin_alpha, o.keep_value = int(bool(argmin_alpha)), int(self.keep_value)
         o.staged_line_search = int(staged_line_search)  # -1 auto, 0 one launch, 1 staged (same results)
+        o.no_fusion = int(bool(no_fusion))              # True: quadratise and backward pass always as two launches
         self._opt = o
         self._ws = self._make_ws()
         self._initialised = False
@@ -212,6 +213,12 @@ class BatchedILQR:
         check(lib().trajopt_ilqr_init_rollout(C.byref(self._struct), C.byref(self._opt), C.byref(self._ws), stream_ptr()))
         self._trace_bound = 1            # trace[0] = the initial return (ilqr.py:149)
         self._initialised = True
+
+    def plan(self):
+        """What an iteration launches: dict(structured_cost, fused_quad_bwd, staged_line_search, backward_kernel)."""
+        pl = _lib.ILQRPlan()
+        check(lib().trajopt_ilqr_plan(C.byref(self._struct), C.byref(self._opt), C.byref(self._ws), C.byref(pl)))
+        return {k: int(getattr(pl, k)) for k, _ in pl._fields_}
 
     def iterate(self, nb_iter=1):
         """`nb_iter` iterations of ilqr.py:151-231 for every problem still running; asynchronous."""
