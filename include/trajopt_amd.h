@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TRAJOPT_ABI_VERSION 4
+#define TRAJOPT_ABI_VERSION 5
 
 #define TRAJOPT_OK 0
 #define TRAJOPT_ERR_BAD_ARG (-1)      /* null pointer, non-positive size, unknown enum            */
@@ -137,6 +137,13 @@ typedef struct trajopt_backward_io {
      * run every family against the oracle) and returns TRAJOPT_ERR_UNSUPPORTED where it has no kernel for the shape. */
     int32_t kernel;
     int32_t pad_;
+    /* Optional double-buffered gains (ABI v5; the batched driver's, NULL for everybody else).  With out_bank
+     * non-NULL, K and kff hold TWO banks each and problem p's gains are written to bank out_bank[p] (0 or 1):
+     *   PROBLEM_MINOR  K(p, e, t, b) = K[((2 t + b) m n + e) nb_problems + p]      (banks interleaved per time step)
+     *   PROBLEM_MAJOR  K(p, e, t, b) = K[(b nb_problems + p) m n T + m n t + e]    (bank slowest)
+     * and the same for kff with m in place of m n.  The other bank of a problem is left untouched: it holds the gains
+     * of its last ACCEPTED iterate while a new candidate is computed (ilqr.py:214 without a copy). */
+    const int32_t* out_bank;
 } trajopt_backward_io_t;
 
 #define TRAJOPT_KERNEL_AUTO 0
@@ -387,10 +394,24 @@ typedef struct trajopt_ilqr_workspace {
     int32_t* cand_finite;
     int32_t* pending_list;   /* [nb_problems], staged line search only (may be NULL otherwise) */
     int32_t* pending_count;  /* [1] */
+    /* ABI v5: no copy on accept.  cand_state / cand_action hold 2 * nb_alphas planes (two banks of nb_alphas) and
+     * cand_K / cand_kff two banks (layout: trajopt_backward_io_t::out_bank).  An iteration writes its candidates and
+     * gains into bank wbank[p] and reads the reference trajectory of problem p from plane ref_plane[p]; accepting
+     * alpha k is  ref_plane[p] = wbank[p] * nb_alphas + k, wbank[p] ^= 1  (ilqr.py:210-217).  Neighbouring problems
+     * read different planes, so a plane is TIME-BLOCKED - 8 consecutive steps of one element of one problem are one
+     * 64-byte run, which its reader uses in full:
+     *     plane(p, e, t) = plane[(((t / 8) rows + e) nb_problems + p) 8 + t % 8],
+     *     plane size = ceil(slices / 8) * 8 * rows * nb_problems   (state: rows n, slices T + 1; action: m, T).
+     * ref_plane[p] < 0 (a fresh workspace) means "the reference is in xref / uref": the driver then plants it into
+     * plane 0.  xref / K / kff are brought up to date once, at the end of every trajopt_ilqr_iterate call (uref in
+     * every iteration); between calls they may be read, not written - trajopt_ilqr_init_rollout re-arms both arrays. */
+    int32_t* ref_plane;      /* [nb_problems] */
+    int32_t* wbank;          /* [nb_problems] */
 } trajopt_ilqr_workspace_t;
 
 /* ilqr.py:139-149: initial rollout of ws->K / ws->kff over the alphas; first one with all(state < 1e8)
- * becomes xref/uref/last_return and trace[0]. */
+ * becomes xref/uref/last_return and trace[0].  Also copies ws->K / ws->kff into bank 0 of cand_K / cand_kff and
+ * initialises ref_plane / wbank. */
 int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
                               const trajopt_ilqr_workspace_t* ws, void* stream);
 /* `nb_iter` iterations of ilqr.py:151-231 for every problem whose status is 0, without any host

@@ -1,0 +1,22 @@
+"""Developer aid: device time of each phase, iteration by iteration, next to the spread of ref_plane / wbank."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from trajopt_amd import _lib, envs
+from trajopt_amd.ilqr import BatchedILQR
+from bench import make_problem_set, PHASES
+env = envs.make("cartpole", dt=0.02, uw=1e-5)
+N, T = int(os.environ.get("NP", 4096)), 500
+x0, kff0 = make_problem_set(env, N, T, 1337)
+s = BatchedILQR(env, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False, tolfun=-float("inf"), tolgrad=0.0,
+                max_lmbda=float("inf"), no_fusion=bool(int(os.environ.get("NOFUSE", 0))))
+L = _lib.lib()
+s.init_rollout(); torch.cuda.synchronize()
+for it in range(int(os.environ.get("ITERS", 16))):
+    _lib.check(L.trajopt_profile_begin(1)); s.iterate(1); torch.cuda.synchronize()
+    ms = (C.c_double * 6)(); n = C.c_int(0)
+    _lib.check(L.trajopt_profile_end(ms, C.byref(n)))
+    ref = s._ref_plane.cpu().numpy(); wb = s._wbank.cpu().numpy()
+    runs = int((np.diff(ref) != 0).sum()) + 1
+    print(it, {k: round(ms[i], 3) for i, k in enumerate(PHASES) if k in ("backward", "quadratize", "rollout", "select_commit")},
+          "planes", np.bincount(ref[ref >= 0], minlength=22).tolist(), "runs of equal plane", runs, "wbank1", int(wb.sum()))

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared_functions():
         assert hasattr(L, name), name
-    assert L.trajopt_abi_version() == _lib.ABI_VERSION == 4
+    assert L.trajopt_abi_version() == _lib.ABI_VERSION == 5
     assert L.trajopt_error_string(-4).decode().startswith("no HIP device")
 
 
@@ -43,10 +43,10 @@ def test_struct_layouts_match_the_c_header():
 #include "trajopt_amd.h"
 int main(void) {
   printf("env %zu %zu %zu %zu\n", sizeof(trajopt_env_t), offsetof(trajopt_env_t, dt), offsetof(trajopt_env_t, lin_A), offsetof(trajopt_env_t, phys));
-  printf("io %zu %zu %zu %zu\n", sizeof(trajopt_backward_io_t), offsetof(trajopt_backward_io_t, dV), offsetof(trajopt_backward_io_t, active), offsetof(trajopt_backward_io_t, kernel));
+  printf("io %zu %zu %zu %zu\n", sizeof(trajopt_backward_io_t), offsetof(trajopt_backward_io_t, dV), offsetof(trajopt_backward_io_t, active), offsetof(trajopt_backward_io_t, out_bank));
   printf("opt %zu %zu %zu %zu\n", sizeof(trajopt_ilqr_options_t), offsetof(trajopt_ilqr_options_t, alphas), offsetof(trajopt_ilqr_options_t, keep_value), offsetof(trajopt_ilqr_options_t, no_fusion));
   printf("plan %zu\n", sizeof(trajopt_ilqr_plan_t));
-  printf("ws %zu %zu %zu %zu\n", sizeof(trajopt_ilqr_workspace_t), offsetof(trajopt_ilqr_workspace_t, trace_cap), offsetof(trajopt_ilqr_workspace_t, A), offsetof(trajopt_ilqr_workspace_t, cand_finite));
+  printf("ws %zu %zu %zu %zu\n", sizeof(trajopt_ilqr_workspace_t), offsetof(trajopt_ilqr_workspace_t, trace_cap), offsetof(trajopt_ilqr_workspace_t, A), offsetof(trajopt_ilqr_workspace_t, wbank));
   return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
@@ -56,10 +56,10 @@ int main(void) {
         got = subprocess.check_output([exe]).decode().split("\n")
     E, IO, OP, WS = _lib.EnvStruct, _lib.BackwardIO, _lib.ILQROptions, _lib.ILQRWorkspace
     assert got[0] == "env %d %d %d %d" % (C.sizeof(E), E.dt.offset, E.lin_A.offset, E.phys.offset)
-    assert got[1] == "io %d %d %d %d" % (C.sizeof(IO), IO.dV.offset, IO.active.offset, IO.kernel.offset)
+    assert got[1] == "io %d %d %d %d" % (C.sizeof(IO), IO.dV.offset, IO.active.offset, IO.out_bank.offset)
     assert got[2] == "opt %d %d %d %d" % (C.sizeof(OP), OP.alphas.offset, OP.keep_value.offset, OP.no_fusion.offset)
     assert got[3] == "plan %d" % C.sizeof(_lib.ILQRPlan)
-    assert got[4] == "ws %d %d %d %d" % (C.sizeof(WS), WS.trace_cap.offset, WS.A.offset, WS.cand_finite.offset)
+    assert got[4] == "ws %d %d %d %d" % (C.sizeof(WS), WS.trace_cap.offset, WS.A.offset, WS.wbank.offset)
     assert C.sizeof(O.EnvStruct) == C.sizeof(E)   # the oracle's mirror of the same POD
 
 

@@ -8,12 +8,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libtrajopt_amd.so")
+SO_PATH = os.environ.get("TRAJOPT_AMD_SO") or os.path.join(_HERE, "libtrajopt_amd.so")
 
 LAYOUT_PROBLEM_MAJOR = 0
 LAYOUT_PROBLEM_MINOR = 1
 MAX_ALPHAS = 16
-ABI_VERSION = 4          # include/trajopt_amd.h::TRAJOPT_ABI_VERSION
+ABI_VERSION = 5          # include/trajopt_amd.h::TRAJOPT_ABI_VERSION
 MAX_STATE, MAX_ACT = 12, 4
 
 ENV_PENDULUM, ENV_CARTPOLE, ENV_DOUBLE_CARTPOLE, ENV_LQR, ENV_QUADROTOR, ENV_DOUBLE_PENDULUM, ENV_ROBOT, ENV_QUAD_PENDULUM = 1, 2, 3, 4, 5, 6, 7, 8
@@ -52,7 +52,7 @@ class BackwardIO(C.Structure):
                   "Qxx", "Qux", "Quu", "qx", "qu", "V", "v", "dV", "K", "kff", "diverge",
                   "uref", "g_norm", "active", "cost_w")] +
                 [("cost_gxx", C.c_double * MAX_STATE), ("cost_guu", C.c_double * MAX_ACT),
-                 ("kernel", C.c_int32), ("pad_", C.c_int32)])
+                 ("kernel", C.c_int32), ("pad_", C.c_int32), ("out_bank", _dp)])
 
 
 class GpsBackwardIO(C.Structure):
@@ -94,7 +94,8 @@ class ILQRWorkspace(C.Structure):
                 [(k, _dp) for k in
                  ("A", "B", "Cxx", "cx", "Cuu", "cu", "Cxu", "cand_K", "cand_kff", "cand_V", "cand_v", "cand_Qxx",
                   "cand_Qux", "cand_Quu", "cand_qx", "cand_qu", "dV", "g_norm", "diverge", "active", "sel",
-                  "cand_state", "cand_action", "cand_ret", "cand_finite", "pending_list", "pending_count")])
+                  "cand_state", "cand_action", "cand_ret", "cand_finite", "pending_list", "pending_count",
+                  "ref_plane", "wbank")])
 
 
 # every symbol include/trajopt_amd.h declares

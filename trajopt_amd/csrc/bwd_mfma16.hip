@@ -37,6 +37,14 @@ __device__ __forceinline__ size_t at(size_t eps, size_t slices, int t, size_t e,
     return MINOR ? (eps * (size_t)t + e) * NP + p : p * eps * slices + eps * (size_t)t + e;
 }
 
+// the same for the gains K / kff, which may hold two banks (trajopt_backward_io_t::out_bank; kmul = 2 with banks)
+template <bool MINOR>
+__device__ __forceinline__ size_t at_gain(size_t eps, size_t slices, int t, size_t e, size_t p, size_t NP, int kmul,
+                                          int bank) {
+    return MINOR ? (eps * (size_t)(kmul * t + bank) + e) * NP + p
+                 : ((size_t)bank * NP + p) * eps * slices + eps * (size_t)t + e;
+}
+
 __device__ __forceinline__ double xor_sum(double x) {  // sum over the four 16-lane rows: lanes c, c+16, c+32, c+48
     x += __shfl_xor(x, 16, 64);
     x += __shfl_xor(x, 32, 64);
@@ -82,6 +90,7 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
     const bool live = c < n;
     const bool want_gn = io.uref != nullptr && io.g_norm != nullptr;
+    const int kmul = io.out_bank ? 2 : 1, bank = gains_bank(io.out_bank, p);
     // F in B layout: Fb[s] = F[4s + g][c] is one slot walked with a fixed row offset of 4 rows per k-step
     const ptrdiff_t row4 = MINOR ? (ptrdiff_t)(4 * NP) : 4;
 
@@ -276,8 +285,8 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
             Wd = __builtin_amdgcn_mfma_f64_16x16x4f64(Qg, Kg, Wd, 0, 0, 0);
 
             // gains out
-            if (live && g < M) io.K[at<MINOR>(nm, T, t, g + (size_t)m * c, p, NP)] = Kg;
-            if (c == 0 && g < M) io.kff[at<MINOR>(m, T, t, g, p, NP)] = kfg;
+            if (live && g < M) io.K[at_gain<MINOR>(nm, T, t, g + (size_t)m * c, p, NP, kmul, bank)] = Kg;
+            if (c == 0 && g < M) io.kff[at_gain<MINOR>(m, T, t, g, p, NP, kmul, bank)] = kfg;
             if (want_gn && g == 0 && c < m) gmax = nanmax(gmax, fabs(pick<M>(kf, c)) / (fabs(ur) + 1.0));
 
             __syncthreads();  // gains have read sQ / sq

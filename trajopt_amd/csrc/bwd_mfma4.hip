@@ -110,6 +110,9 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
         return M4Off{o0.rc + tn * s_nn, o0.r + tn * s_n, o0.c + tn * s_n, o0.z + tn * s_1};
     };
     auto back = [&](M4Off& o) { o.rc -= s_nn; o.r -= s_n; o.c -= s_n; o.z -= s_1; };
+    // gains: bank io.out_bank[p] of the two interleaved per time step (trajopt_backward_io_t::out_bank); du = 1
+    const unsigned kmul = a.io.out_bank ? 2u : 1u, bank = (unsigned)gains_bank(a.io.out_bank, p);
+    const unsigned gK0 = (bank * N + cc) * np8 + p8, gk0 = bank * np8 + p8, gs_n = kmul * s_n, gs_1 = kmul * s_1;
     // Stores need no lane predicate for N = 4: a value replicated over r (or c, or the whole block) is written by
     // all its holders to the one address - same value, same address, merged by the memory pipeline.
     const bool st_rc = (N == 4) || in_rc, st_r = (N == 4) || in_r, st_c = (N == 4) || in_c;
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
             VT = m4_mm(VTerm, eye, 0.0);
         }
         M4Off ol = slice(T - 1), os = ol;  // slice being loaded / slice being computed and stored
+        unsigned gK = gK0 + (unsigned)(T - 1) * gs_n, gk = gk0 + (unsigned)(T - 1) * gs_1;  // K[c], kff of that slice
         const char* pl = p_base + p_off + (size_t)(T - 1) * p_stride;  // the lane's slot of P in the slice being loaded
         M4In ring[kRing];
 #pragma unroll
@@ -256,8 +260,8 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
                 VT = fma(QuuF, KR * KC, fma(0.5, Qs, cross));             // util.cpp:159-161
             }
             if (alive) {
-                if (st_c) m4_st(KC, io.K, os.c);
-                m4_st(kff, io.kff, os.z);
+                if (st_c) m4_st(KC, io.K, gK);
+                m4_st(kff, io.kff, gk);
                 if constexpr (FULL) {
                     if (st_rc && io.V) m4_st(VT, io.V, os.rc);
                     if (st_r && io.v) m4_st(vR, io.v, os.r);
@@ -272,6 +276,8 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
                 }
             }
             back(os);
+            gK -= gs_n;
+            gk -= gs_1;
         };
 
         // Slot k of the ring holds step t; once consumed it is refilled IN PLACE with step t - kRing (a refill issued

@@ -93,7 +93,8 @@ __device__ __forceinline__ void load_step(StepIn<N, M>& s, const TppArgs& a, siz
 template <int N, int M, bool FULL, bool GN>
 __device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N * N], double (&v)[N], double lam,
                                          int reg, double& dV0, double& dV1, double (&gmax)[M], const TppArgs& a,
-                                         size_t p0, const Lane& off, int t) {
+                                         size_t p0, const Lane& off, const Lane& offK, const Lane& offkff, int kmul,
+                                         int t) {
     const size_t NP = a.NP;
     (void)NP;
     // W = V A, Z = V B
@@ -296,8 +297,9 @@ __device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N *
         for (int i = 0; i < N; ++i) V[i + N * j] = 0.5 * (W[i + N * j] + W[j + N * i]);
 
     // stores
-    store_vec<M * N>(UBASE(a.io.K, N * M, t), off, K);
-    store_vec<M>(UBASE(a.io.kff, M, t), off, kff);
+    // (the lane's bank of the double-buffered gains is part of offK / offkff: trajopt_backward_io_t::out_bank)
+    store_vec<M * N>(UBASE(a.io.K, kmul * N * M, t), offK, K);
+    store_vec<M>(UBASE(a.io.kff, kmul * M, t), offkff, kff);
     if constexpr (FULL) {
         if (a.io.V) store_vec<N * N>(UBASE(a.io.V, N * N, t), off, V);
         if (a.io.v) store_vec<N>(UBASE(a.io.v, N, t), off, v);
@@ -319,6 +321,9 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
     const size_t NP = a.NP;
     const int T = a.T;
     const Lane off{lane * 8u, NP};  // host guarantees N*N*NP*8 + 512 < 2^32
+    const int kmul = a.io.out_bank ? 2 : 1;
+    const unsigned bank = (unsigned)gains_bank(a.io.out_bank, p);
+    const Lane offK{lane * 8u + bank * (unsigned)(N * M * NP * 8), NP}, offkff{lane * 8u + bank * (unsigned)(M * NP * 8), NP};
     double lam = a.io.lmbda[p];
     double dlam = (a.retry && a.io.dlmbda) ? a.io.dlmbda[p] : 1.0;
     int div = -1, retries = 0;
@@ -357,14 +362,14 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
         load_step<N, M, GN, SC>(s0, a, p0, off, t);
         while (t >= 0) {
             load_step<N, M, GN, SC>(s1, a, p0, off, t >= 1 ? t - 1 : 0);
-            if (!bwd_step<N, M, FULL, GN>(s0, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, t)) {
+            if (!bwd_step<N, M, FULL, GN>(s0, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) {
                 div = t;
                 break;
             }
             --t;
             if (t < 0) break;
             load_step<N, M, GN, SC>(s0, a, p0, off, t >= 1 ? t - 1 : 0);
-            if (!bwd_step<N, M, FULL, GN>(s1, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, t)) {
+            if (!bwd_step<N, M, FULL, GN>(s1, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) {
                 div = t;
                 break;
             }

@@ -53,6 +53,12 @@ __global__ __launch_bounds__(256) void bwd_wg_kernel(WgArgs a) {
     const size_t p = blockIdx.x;
     if (VARIANT == 0 && a.io.active && a.io.active[p] == 0) return;
     const G<MINOR> g{a.NP, p};
+    // gains K / kff: bank io.out_bank[p] of two when the driver double-buffers them (trajopt_backward_io_t::out_bank)
+    const int kmul = (VARIANT == 0 && a.io.out_bank) ? 2 : 1, bank = VARIANT == 0 ? gains_bank(a.io.out_bank, p) : 0;
+    auto gK = [&](size_t eps, size_t slices, int t, size_t e) -> size_t {
+        return MINOR ? (eps * (size_t)(kmul * t + bank) + e) * a.NP + p
+                     : ((size_t)bank * a.NP + p) * eps * slices + eps * (size_t)t + e;
+    };
     const int nn = n * n, nm = n * m, mm = m * m;
     const size_t Enn1 = (size_t)nn * (T + 1), Enm1 = (size_t)nm * (T + 1), Emm1 = (size_t)mm * (T + 1);
     const size_t En1 = (size_t)n * (T + 1), Em1 = (size_t)m * (T + 1);
@@ -272,8 +278,8 @@ __global__ __launch_bounds__(256) void bwd_wg_kernel(WgArgs a) {
                     }
                     sW[e] = s;
                 }
-                for (int e = tid; e < nm; e += BS) io.K[g((size_t)nm * t + e, Enm)] = sK[e];
-                for (int e = tid; e < m; e += BS) io.kff[g((size_t)m * t + e, Em)] = skff[e];
+                for (int e = tid; e < nm; e += BS) io.K[gK(nm, T, t, e)] = sK[e];
+                for (int e = tid; e < m; e += BS) io.kff[gK(m, T, t, e)] = skff[e];
                 __syncthreads();
                 // P7: symmetrise (util.cpp:161)
                 for (int e = tid; e < nn; e += BS) {
@@ -354,8 +360,8 @@ __global__ __launch_bounds__(256) void bwd_wg_kernel(WgArgs a) {
                     s = fma(2.0, s, sqx[i]);
                     svv[i] = s;  // sv is still read by nobody, but keep the write after the barrier
                 }
-                for (int e = tid; e < nm; e += BS) io.K[g((size_t)nm * t + e, Enm)] = sK[e];
-                for (int e = tid; e < m; e += BS) io.kff[g((size_t)m * t + e, Em)] = skff[e];
+                for (int e = tid; e < nm; e += BS) io.K[gK(nm, T, t, e)] = sK[e];
+                for (int e = tid; e < m; e += BS) io.kff[gK(m, T, t, e)] = skff[e];
                 __syncthreads();
                 for (int e = tid; e < nn; e += BS) {
                     sV[e] = sW[e];

@@ -39,14 +39,42 @@ __device__ __forceinline__ double rcp_nr(double x) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Fused commit of the previous iteration's line search (driver only; ilqr.py:210-217): where sel[p] >= 0 the reference
-// trajectory is read from candidate plane sel[p] and written through to xref / uref, and the candidate gains are promoted
-// to K / kff.  Used by the quadratisation kernel and by the fused quadratise + backward kernel.
-struct QuadCommit {
-    const int32_t* sel;
-    const double *cand_state, *cand_action, *cand_K, *cand_kff;
-    double *xref, *uref, *K, *kff;
+// ---- the batched driver's candidate planes (trajopt_ilqr_workspace_t::cand_state / cand_action, ABI v5) ------------
+// Accepting a candidate copies nothing (ilqr.py:210-217): problem p's reference trajectory IS candidate plane
+// ref_plane[p].  Neighbouring problems accept different step sizes, i.e. read different planes, so a plane must not
+// put neighbouring problems into one cache line (a reader would use 8 bytes of every 128-byte line: measured, the
+// rollout ran at half speed on the plain struct-of-arrays planes).  The planes are therefore TIME-BLOCKED: element e
+// of steps 8 b .. 8 b + 7 of one problem is one 64-byte run,
+//     plane[(((t / 8) * rows + e) * nb_problems + p) * 8 + t % 8],      plane size = ceil(slices / 8) * 8 * rows * nb_problems,
+// which a reader of that problem uses in full over 8 consecutive steps, whatever plane its neighbours read.
+constexpr int kTB = 8;
+__host__ __device__ inline size_t tb_blocks(int slices) { return (size_t)(slices + kTB - 1) / kTB; }
+__host__ __device__ inline size_t tb_plane(int rows, int slices, size_t NP) { return tb_blocks(slices) * kTB * (size_t)rows * NP; }
+__host__ __device__ inline size_t tb_index(int rows, int t, int e, size_t p, size_t NP) {
+    return ((((size_t)(t / kTB) * rows + e) * NP + p) * kTB) + (size_t)(t % kTB);
+}
+
+// Where the driver's quadratisation finds the reference trajectory: states / actions of problem p in time-blocked
+// plane ref_plane[p] (>= 0 for every problem once trajopt_ilqr_init_rollout / the driver's plant step has run) of
+// cand_state / cand_action.  xref_out / uref_out: what it read is written through to these dense PROBLEM_MINOR arrays
+// (the workspace's xref / uref), from which the backward pass (gradient norm, ilqr.py:176) and the rollout - whose
+// lanes of one problem sit in eleven different waves - take the reference with wave-uniform, coalesced addressing.
+struct RefView {
+    const int32_t* ref_plane;  // NULL: the dense xref / uref arrays the kernel is given, for every problem
+    const double *cand_state, *cand_action;
+    double *xref_out, *uref_out;
 };
+
+// The rollout's side of the same scheme: its candidates go, time-blocked, into bank wbank[p] (of `planes` planes
+// each; bank 0 without wbank) of cand_state / cand_action, and it reads the gains from that bank of the
+// double-buffered K / kff.  Its reference comes from the dense xref / uref the quadratisation writes through.
+struct RolloutBanks {
+    const int32_t* wbank;
+    int planes;
+};
+
+// Bank of the double-buffered gains problem p writes (trajopt_backward_io_t::out_bank), 0 without banks.
+__device__ __forceinline__ int gains_bank(const int32_t* out_bank, size_t p) { return out_bank ? (out_bank[p] & 1) : 0; }
 
 // Kernel launchers implemented per translation unit (all return TRAJOPT_* codes).
 int launch_backward_tpp(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int retry,

@@ -1,12 +1,14 @@
 // Batched iLQR driver (row A6): the per-problem control flow of iLQR.run,
 // /root/reference/trajopt/ilqr/ilqr.py:136-237, kept entirely on the device.
 //
-// An iteration is seven launches on one stream and no host synchronisation:
-//   prep -> quadratise -> backward pass (lambda retries inside the kernel, ilqr.py:162-173)
-//        -> gradient-norm stop (ilqr.py:176-180) -> rollout of every alpha at once (ilqr.py:187-191)
-//        -> first-accept selection + lambda update + stopping rules (ilqr.py:193-231) -> commit.
-// Problems that have stopped keep their slot and are masked out through `active`.
-// Everything is PROBLEM_MINOR except the gains group (ws->gains_layout, see include/trajopt_amd.h).
+// An iteration is four or five launches on one stream and no host synchronisation:
+//   quadratise -> backward pass (lambda retries inside the kernel, ilqr.py:162-173)   [one fused launch for small
+//        dx <= 4 batches] -> gradient-norm stop (ilqr.py:176-180) -> rollout of every alpha at once (ilqr.py:187-191)
+//        -> first-accept selection + lambda update + stopping rules (ilqr.py:193-231).
+// Accepting a candidate (ilqr.py:210-217) copies nothing: candidates and gains are double-buffered per problem and an
+// accept only moves ref_plane[p] / wbank[p] (include/trajopt_amd.h, ABI v5); xref / K / kff are brought up to date once
+// per trajopt_ilqr_iterate call.  Problems that have stopped keep their slot and are masked out through `active`
+// (SURVEY 9.5).  Everything is PROBLEM_MINOR except the gains group (ws->gains_layout, see include/trajopt_amd.h).
 #include "sys.h"
 
 namespace trajopt {
@@ -15,17 +17,17 @@ int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, cons
                    const double* kff, const double* xref, const double* uref, const double* weighting,
                    const double* alphas_host, int nb_alphas, const int32_t* active, double* state, double* action,
                    double* cost, double* ret, int32_t* finite, hipStream_t st, int k_layout, int alpha_begin,
-                   int alpha_end, const int32_t* plist, const int32_t* pcount);
+                   int alpha_end, const int32_t* plist, const int32_t* pcount, const RolloutBanks* banks);
 int launch_quadratize(const trajopt_env_t* env, int T, int64_t NP, int layout, int convention, const double* xref,
                       const double* uref, const double* weighting, const int32_t* active, double* A, double* B,
                       double* c, double* Cxx, double* cx, double* Cuu, double* cu, double* Cxu, hipStream_t st,
-                      const QuadCommit* cm, int out_layout);
+                      const RefView* rv, int out_layout);
 
 bool fused_qb4_supported(const trajopt_env_t* env, int T, int64_t NP);
 int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want);
 int launch_fused_qb4(const trajopt_env_t* env, const trajopt_backward_io_t& io, int reg, int T, int64_t NP, int retry,
                      const trajopt_lambda_schedule_t& sched, const double* xref, const double* uref,
-                     const QuadCommit* cm, hipStream_t st);
+                     const RefView* rv, hipStream_t st);
 
 struct DrvArgs {
     trajopt_ilqr_options_t opt;
@@ -60,6 +62,10 @@ __global__ void init_select_kernel(DrvArgs a) {
     for (int k = 0; k < a.opt.nb_alphas; ++k)
         if (a.ws.cand_finite[(size_t)k * NP + p] && isfinite(a.ws.cand_ret[(size_t)k * NP + p])) { sel = k; break; }
     a.ws.sel[p] = sel;
+    // the initial rollout wrote its candidates into bank 0: the reference is plane `sel` there (none finite: whatever
+    // xref / uref hold), and the first iteration writes bank 1
+    a.ws.ref_plane[p] = sel;
+    a.ws.wbank[p] = 1;
     // no finite alpha: last_return keeps its previous value (-inf on a fresh solver, ilqr.py:87)
     const double r = sel >= 0 ? a.ws.cand_ret[(size_t)sel * NP + p] : a.ws.last_return[p];
     a.ws.last_return[p] = r;
@@ -114,7 +120,12 @@ __global__ void pending_kernel(DrvArgs a) {
     double dV0, dV1;
     load_dV(a, p, NP, dV0, dV1);
     const double expected = -1.0 * alpha * (dV0 + alpha * dV1);
-    if (!(dret / expected >= a.opt.min_imp)) {
+    const bool accepted = dret / expected >= a.opt.min_imp;
+    // the decision is RECORDED (sel: 0 = alphas[0] accepted, -1 = pending) and select_kernel takes it from there
+    // instead of evaluating the test a second time: nothing forces two compilations of it to round alike, and a
+    // problem left off the list but rejected by select would go on to read the stale returns of the other alphas
+    a.ws.sel[p] = accepted ? 0 : -1;
+    if (!accepted) {
         const int j = atomicAdd(a.ws.pending_count, 1);
         a.ws.pending_list[j] = (int32_t)p;
     }
@@ -123,15 +134,17 @@ __global__ void pending_kernel(DrvArgs a) {
 // ilqr.py:187-231: sequential first-accept over the alphas, evaluated from the precomputed returns.
 // prep_next: another iteration follows in this call - its prep (same thread-per-problem mapping, nothing reads `active`
 // in between) is done here instead of in a launch of its own.
-__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP);
-__global__ void select_kernel(DrvArgs a, int prep_next) {
+// staged: pending_kernel has already decided alphas[0] for this problem (sel[p]).
+__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP, int staged);
+__global__ void select_kernel(DrvArgs a, int prep_next, int staged) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t NP = (size_t)a.ws.nb_problems;
     if (p >= NP) return;
-    select_problem(a, p, NP);
+    select_problem(a, p, NP, staged);
     if (prep_next) prep_problem(a, p);
 }
-__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP) {
+__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP, int staged) {
+    const bool first_accepted = staged && a.ws.sel[p] == 0;
     a.ws.sel[p] = -1;
     if (!a.ws.active[p]) return;
     const double last = a.ws.last_return[p];
@@ -159,7 +172,8 @@ __device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_
         const double expected = -1.0 * alpha * (dV0 + alpha * dV1);
         const double imp = dret / expected;
         if (sel < 0) alpha_last = alpha;  // self.alpha follows the loop variable (ilqr.py:188)
-        if (imp >= a.opt.min_imp) {       // NaN compares false -> rejected
+        const bool ok = (staged && k == 0) ? first_accepted : (imp >= a.opt.min_imp);  // NaN compares false -> rejected
+        if (ok) {
             if (!a.opt.argmin_alpha) { sel = k; dret_sel = dret; break; }
             if (sel < 0 || ret < best) { sel = k; best = ret; dret_sel = dret; alpha_last = alpha; }
         }
@@ -176,6 +190,11 @@ __device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_
         }
         if (dret_sel < a.opt.tolfun) a.ws.status[p] = 2;  // ilqr.py:222
         a.ws.sel[p] = sel;
+        // ilqr.py:210-217 without a copy: the candidate's plane IS the reference from now on, its gains' bank holds
+        // the accepted controller, and the next iteration writes the other bank
+        const int wb = a.ws.wbank[p] & 1;
+        a.ws.ref_plane[p] = wb * a.opt.nb_alphas + sel;
+        a.ws.wbank[p] = wb ^ 1;
     } else {
         grow_lambda(lam, dlam, a.opt.sched);
         if (lam > a.opt.sched.max_lmbda) a.ws.status[p] = 3;  // ilqr.py:228
@@ -185,47 +204,88 @@ __device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_
     a.ws.dlmbda[p] = dlam;
 }
 
-// Copy the accepted candidate into the reference slots (ilqr.py:210-217 / :142-143).  Thread per
-// (problem, step); `with_ctl` also promotes the candidate gains (and value functions if kept).
+// Index of element e of step t of problem p in a gains-group array (eps elements per step, `slices` steps).
 template <bool GMINOR>
 __device__ __forceinline__ size_t gidx(size_t eps, size_t slices, int t, size_t e, size_t p, size_t NP) {
     return GMINOR ? (eps * (size_t)t + e) * NP + p : p * eps * slices + eps * (size_t)t + e;
 }
-
+// The same inside bank b of the double-buffered cand_K / cand_kff (trajopt_backward_io_t::out_bank).
 template <bool GMINOR>
-__global__ void commit_kernel(DrvArgs a, int with_ctl) {
+__device__ __forceinline__ size_t gidx_bank(size_t eps, size_t slices, int t, size_t e, size_t p, size_t NP, int b) {
+    return GMINOR ? (eps * (size_t)(2 * t + b) + e) * NP + p : ((size_t)b * NP + p) * eps * slices + eps * (size_t)t + e;
+}
+
+// Bring xref / uref (and, with_ctl, K / kff) up to date with the accepted iterate (ilqr.py:210-217 / :142-143): copy
+// plane ref_plane[p] and the gains of its bank.  Thread per (problem, step); once per driver call, not per iteration.
+template <bool GMINOR>
+__global__ void publish_kernel(DrvArgs a, int with_ctl) {
     const size_t NP = (size_t)a.ws.nb_problems;
     const int T = a.ws.nb_steps, n = a.n, m = a.m;
     // grid = (problem blocks, T + 1): no 64-bit division in the index math
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int t = (int)blockIdx.y;
     if (p >= NP) return;
-    const int sel = a.ws.sel[p];
-    if (sel < 0) return;
-    const double* st = a.ws.cand_state + (size_t)sel * (size_t)n * (T + 1) * NP;
-    for (int i = 0; i < n; ++i) a.ws.xref[((size_t)n * t + i) * NP + p] = st[((size_t)n * t + i) * NP + p];
-    if (t < T) {
-        const double* ac = a.ws.cand_action + (size_t)sel * (size_t)m * T * NP;
-        for (int j = 0; j < m; ++j) a.ws.uref[((size_t)m * t + j) * NP + p] = ac[((size_t)m * t + j) * NP + p];
-    }
+    const int ref = a.ws.ref_plane[p];
+    if (ref < 0) return;
+    const double* st = a.ws.cand_state + (size_t)ref * tb_plane(n, T + 1, NP);
+    for (int i = 0; i < n; ++i) a.ws.xref[((size_t)n * t + i) * NP + p] = st[tb_index(n, t, i, p, NP)];
+    if (t >= T) return;
+    const double* ac = a.ws.cand_action + (size_t)ref * tb_plane(m, T, NP);
+    for (int j = 0; j < m; ++j) a.ws.uref[((size_t)m * t + j) * NP + p] = ac[tb_index(m, t, j, p, NP)];
     if (!with_ctl) return;
+    const int b = ref / a.opt.nb_alphas;
+    const size_t nm = (size_t)n * m;
+    for (size_t k = 0; k < nm; ++k) a.ws.K[gidx<GMINOR>(nm, T, t, k, p, NP)] = a.ws.cand_K[gidx_bank<GMINOR>(nm, T, t, k, p, NP, b)];
+    for (size_t k = 0; k < (size_t)m; ++k) a.ws.kff[gidx<GMINOR>(m, T, t, k, p, NP)] = a.ws.cand_kff[gidx_bank<GMINOR>(m, T, t, k, p, NP, b)];
+}
+
+// The reverse, for a problem whose reference is not in a plane yet (ref_plane[p] < 0: no finite initial rollout,
+// ilqr.py:139-147, or a workspace handed to trajopt_ilqr_iterate without trajopt_ilqr_init_rollout): xref / uref / K /
+// kff are planted into plane 0 and gains bank 0, and plant_finish_kernel then points the problem there.
+template <bool GMINOR>
+__global__ void plant_kernel(DrvArgs a) {
+    const size_t NP = (size_t)a.ws.nb_problems;
+    const int T = a.ws.nb_steps, n = a.n, m = a.m;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = (int)blockIdx.y;
+    if (p >= NP) return;
+    if (a.ws.ref_plane[p] >= 0) return;
+    for (int i = 0; i < n; ++i) a.ws.cand_state[tb_index(n, t, i, p, NP)] = a.ws.xref[((size_t)n * t + i) * NP + p];
+    if (t >= T) return;
+    for (int j = 0; j < m; ++j) a.ws.cand_action[tb_index(m, t, j, p, NP)] = a.ws.uref[((size_t)m * t + j) * NP + p];
+    const size_t nm = (size_t)n * m;
+    for (size_t k = 0; k < nm; ++k) a.ws.cand_K[gidx_bank<GMINOR>(nm, T, t, k, p, NP, 0)] = a.ws.K[gidx<GMINOR>(nm, T, t, k, p, NP)];
+    for (size_t k = 0; k < (size_t)m; ++k) a.ws.cand_kff[gidx_bank<GMINOR>(m, T, t, k, p, NP, 0)] = a.ws.kff[gidx<GMINOR>(m, T, t, k, p, NP)];
+}
+__global__ void plant_finish_kernel(DrvArgs a) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)a.ws.nb_problems) return;
+    if (a.ws.ref_plane[p] >= 0) return;
+    a.ws.ref_plane[p] = 0;
+    a.ws.wbank[p] = 1;
+}
+
+// keep_value only: promote the value / Q-function arrays of the problems that accepted in this iteration
+// (ilqr.py:214-215).  Thread per (problem, step).
+template <bool GMINOR>
+__global__ void promote_value_kernel(DrvArgs a) {
+    const size_t NP = (size_t)a.ws.nb_problems;
+    const int T = a.ws.nb_steps, n = a.n, m = a.m;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = (int)blockIdx.y;
+    if (p >= NP) return;
+    if (a.ws.sel[p] < 0) return;
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
 #define TJ_COPY(dst, src, eps, slices, cnt) \
     for (size_t k = 0; k < (cnt); ++k) { const size_t o = gidx<GMINOR>(eps, slices, t, k, p, NP); a.ws.dst[o] = a.ws.src[o]; }
+    TJ_COPY(V, cand_V, nn, T + 1, nn)
+    TJ_COPY(v, cand_v, n, T + 1, (size_t)n)
     if (t < T) {
-        TJ_COPY(K, cand_K, nm, T, nm)
-        TJ_COPY(kff, cand_kff, m, T, (size_t)m)
-    }
-    if (a.opt.keep_value) {
-        TJ_COPY(V, cand_V, nn, T + 1, nn)
-        TJ_COPY(v, cand_v, n, T + 1, (size_t)n)
-        if (t < T) {
-            TJ_COPY(Qxx, cand_Qxx, nn, T, nn)
-            TJ_COPY(Qux, cand_Qux, nm, T, nm)
-            TJ_COPY(Quu, cand_Quu, mm, T, mm)
-            TJ_COPY(qx, cand_qx, n, T, (size_t)n)
-            TJ_COPY(qu, cand_qu, m, T, (size_t)m)
-        }
+        TJ_COPY(Qxx, cand_Qxx, nn, T, nn)
+        TJ_COPY(Qux, cand_Qux, nm, T, nm)
+        TJ_COPY(Quu, cand_Quu, mm, T, mm)
+        TJ_COPY(qx, cand_qx, n, T, (size_t)n)
+        TJ_COPY(qu, cand_qu, m, T, (size_t)m)
     }
 #undef TJ_COPY
 }
@@ -241,7 +301,7 @@ __global__ __launch_bounds__(64) void gnorm_major_kernel(DrvArgs a) {
         double mx = -INFINITY;
         bool nan_seen = false;
         for (int t = lane; t < T; t += 64) {
-            const double q = fabs(a.ws.cand_kff[p * (size_t)m * T + (size_t)m * t + j]) /
+            const double q = fabs(a.ws.cand_kff[((size_t)(a.ws.wbank[p] & 1) * NP + p) * (size_t)m * T + (size_t)m * t + j]) /
                              (fabs(a.ws.uref[((size_t)m * t + j) * NP + p]) + 1.0);
             nan_seen = nan_seen || (q != q);
             mx = fmax(mx, q);
@@ -282,7 +342,7 @@ static int check_ws(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
                           ws->dlmbda, ws->alpha, ws->status, ws->iters, ws->trace_len, ws->trace, ws->A, ws->B,
                           ws->Cxx, ws->cx, ws->Cuu, ws->cu, ws->Cxu, ws->cand_K, ws->cand_kff, ws->dV, ws->g_norm,
                           ws->diverge, ws->active, ws->sel, ws->cand_state, ws->cand_action, ws->cand_ret,
-                          ws->cand_finite};
+                          ws->cand_finite, ws->ref_plane, ws->wbank};
     for (const void* q : need)
         if (!q) return TRAJOPT_ERR_BAD_ARG;
     if (opt->keep_value) {
@@ -309,15 +369,33 @@ int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_optio
     if (rc != TRAJOPT_OK) return rc;
     hipStream_t st = as_stream(stream);
     const int64_t NP = ws->nb_problems;
-    const int T = ws->nb_steps;
+    const int T = ws->nb_steps, n = env->dm_state, m = env->dm_act;
+    // candidates go to bank 0 (no wbank given) of the time-blocked planes, the reference is still the dense
+    // xref / uref (no ref_plane given)
+    const RolloutBanks rb{nullptr, opt->nb_alphas};
     rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->K, ws->kff, ws->xref, ws->uref,
                         ws->weighting, opt->alphas, opt->nb_alphas, nullptr, ws->cand_state, ws->cand_action, nullptr,
-                        ws->cand_ret, ws->cand_finite, st, ws->gains_layout, 0, opt->nb_alphas, nullptr, nullptr);
+                        ws->cand_ret, ws->cand_finite, st, ws->gains_layout, 0, opt->nb_alphas, nullptr, nullptr, &rb);
     if (rc != TRAJOPT_OK) return rc;
-    DrvArgs a{*opt, *ws, env->dm_state, env->dm_act};
+    // bank 0 of the double-buffered gains = the controller the reference was rolled out with (K / kff): the bank of
+    // ref_plane[p] then always holds the accepted gains of problem p, accepted iteration or not
+    if (ws->gains_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR) {   // banks interleaved per time step
+        const size_t wK = (size_t)n * m * NP * sizeof(double), wk = (size_t)m * NP * sizeof(double);
+        TRAJOPT_HIP_CHECK(hipMemcpy2DAsync(ws->cand_K, 2 * wK, ws->K, wK, wK, (size_t)T, hipMemcpyDeviceToDevice, st));
+        TRAJOPT_HIP_CHECK(hipMemcpy2DAsync(ws->cand_kff, 2 * wk, ws->kff, wk, wk, (size_t)T, hipMemcpyDeviceToDevice, st));
+    } else {                                                   // bank slowest
+        TRAJOPT_HIP_CHECK(hipMemcpyAsync(ws->cand_K, ws->K, (size_t)n * m * T * NP * sizeof(double), hipMemcpyDeviceToDevice, st));
+        TRAJOPT_HIP_CHECK(hipMemcpyAsync(ws->cand_kff, ws->kff, (size_t)m * T * NP * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    DrvArgs a{*opt, *ws, n, m};
     const unsigned g1 = (unsigned)((NP + 255) / 256);
+    const dim3 g2(g1, (unsigned)(T + 1));
     hipLaunchKernelGGL(init_select_kernel, dim3(g1), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(commit_kernel<true>, dim3(g1, (unsigned)(T + 1)), dim3(256), 0, st, a, 0);
+    hipLaunchKernelGGL(publish_kernel<true>, g2, dim3(256), 0, st, a, 0);   // xref / uref = the accepted rollout
+    // no finite rollout: the reference stays what xref / uref held, planted into plane 0
+    if (ws->gains_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR) hipLaunchKernelGGL(plant_kernel<true>, g2, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(plant_kernel<false>, g2, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(plant_finish_kernel, dim3(g1), dim3(256), 0, st, a);
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
 }
@@ -371,7 +449,6 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         for (int i = 0; i < n; ++i) io.cost_gxx[i] = sc * 2.0 * env->gw[i];
         for (int j = 0; j < m; ++j) io.cost_guu[j] = sc * 2.0 * env->uw[j];
     }
-    const bool fuse_commit = !opt->keep_value;
     const bool fused_qb = structured && gminor && !opt->keep_value && !opt->no_fusion && fused_qb4_supported(env, T, NP);
     // staged line search: worth its second 500-step latency chain, and the scattered accesses of its compacted second
     // stage, only once the one-launch form oversubscribes the chip (1024 SIMDs x 64 lanes) many times over - measured
@@ -380,27 +457,32 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
     bool staged = opt->staged_line_search == 1 ||
                   (opt->staged_line_search < 0 && (int64_t)NP * opt->nb_alphas >= 16 * 65536);
     if (opt->argmin_alpha || opt->nb_alphas < 2 || !ws->pending_list || !ws->pending_count) staged = false;
-    const QuadCommit cm{ws->sel, ws->cand_state, ws->cand_action, ws->cand_K, ws->cand_kff,
-                        ws->xref, ws->uref, ws->K, ws->kff};
+    // No copy on accept: the quadratisation reads the reference through ref_plane (time-blocked planes: whole 64-byte
+    // runs per problem, whatever planes its neighbours read) and writes what it read through to the dense xref / uref,
+    // where the backward kernels' gradient norm and the rollout find it; candidates and gains go to bank wbank[p].
+    const RefView rv{ws->ref_plane, ws->cand_state, ws->cand_action, ws->xref, ws->uref};
+    const RolloutBanks rb{ws->wbank, opt->nb_alphas};
+    io.out_bank = ws->wbank;
+    if (nb_iter > 0) {   // a workspace that never saw trajopt_ilqr_init_rollout: its reference is still in xref / uref
+        if (gminor) hipLaunchKernelGGL(plant_kernel<true>, g2, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(plant_kernel<false>, g2, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(plant_finish_kernel, dim3(g1), dim3(256), 0, st, a);
+    }
     for (int it = 0; it < nb_iter; ++it) {
         const int slot = (g_prof.on && g_prof.used < g_prof.cap) ? g_prof.used++ : -1;
         prof_mark(st, slot, 0);
         if (it == 0) hipLaunchKernelGGL(prep_kernel, dim3(g1), dim3(256), 0, st, a);   // later ones ride in select_kernel
         prof_mark(st, slot, 1);
-        // The accepted candidate of iteration it-1 is promoted to xref/uref/K/kff by this iteration's
-        // quadratisation (it reads every (problem, step) of the trajectory anyway); only the last iteration
-        // of the call, and the keep_value mode, use the stand-alone commit kernel.
-        const QuadCommit* cmp = (fuse_commit && it > 0) ? &cm : nullptr;
         if (fused_qb) {
             // small batches of dx <= 4, du = 1 models: quadratisation and recursion in one launch, the expansion
             // handed over through LDS (fused_qb4.hip); reported under the "backward" phase
             prof_mark(st, slot, 2);
-            rc = launch_fused_qb4(env, io, opt->reg, T, NP, 1, opt->sched, ws->xref, ws->uref, cmp, st);
+            rc = launch_fused_qb4(env, io, opt->reg, T, NP, 1, opt->sched, ws->xref, ws->uref, &rv, st);
             if (rc != TRAJOPT_OK) return rc;
         } else {
             rc = launch_quadratize(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 0, ws->xref, ws->uref, ws->weighting,
                                    ws->active, ws->A, ws->B, nullptr, structured ? nullptr : ws->Cxx, ws->cx,
-                                   structured ? nullptr : ws->Cuu, ws->cu, structured ? nullptr : ws->Cxu, st, cmp, GL);
+                                   structured ? nullptr : ws->Cuu, ws->cu, structured ? nullptr : ws->Cxu, st, &rv, GL);
             if (rc != TRAJOPT_OK) return rc;
             prof_mark(st, slot, 2);
             rc = trajopt_ilqr_backward_pass_batched(&io, opt->reg, n, m, T, NP, GL, 1, &opt->sched, st);
@@ -414,30 +496,36 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
             rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
                                 ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                                 ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 0, opt->nb_alphas,
-                                nullptr, nullptr);
+                                nullptr, nullptr, &rb);
             if (rc != TRAJOPT_OK) return rc;
         } else {
             rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
                                 ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
-                                ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 0, 1, nullptr, nullptr);
+                                ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 0, 1, nullptr, nullptr,
+                                &rb);
             if (rc != TRAJOPT_OK) return rc;
             TRAJOPT_HIP_CHECK(hipMemsetAsync(ws->pending_count, 0, sizeof(int32_t), st));
             hipLaunchKernelGGL(pending_kernel, dim3(g1), dim3(256), 0, st, a);
             rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
                                 ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                                 ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 1, opt->nb_alphas,
-                                ws->pending_list, ws->pending_count);
+                                ws->pending_list, ws->pending_count, &rb);
             if (rc != TRAJOPT_OK) return rc;
         }
         prof_mark(st, slot, 5);
-        hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a, it + 1 < nb_iter ? 1 : 0);
-        if (!fuse_commit || it == nb_iter - 1) {
-            if (gminor) hipLaunchKernelGGL(commit_kernel<true>, g2, dim3(256), 0, st, a, 1);
-            else hipLaunchKernelGGL(commit_kernel<false>, g2, dim3(256), 0, st, a, 1);
+        hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a, it + 1 < nb_iter ? 1 : 0, staged ? 1 : 0);
+        if (opt->keep_value) {
+            if (gminor) hipLaunchKernelGGL(promote_value_kernel<true>, g2, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(promote_value_kernel<false>, g2, dim3(256), 0, st, a);
+        }
+        if (it == nb_iter - 1) {   // xref / uref / K / kff of the accepted iterate, once per call
+            if (gminor) hipLaunchKernelGGL(publish_kernel<true>, g2, dim3(256), 0, st, a, 1);
+            else hipLaunchKernelGGL(publish_kernel<false>, g2, dim3(256), 0, st, a, 1);
         }
         prof_mark(st, slot, 6);
+        // a failed launch is reported in the iteration it happens in, not after the remaining ones ran on its garbage
+        TRAJOPT_HIP_CHECK(hipGetLastError());
     }
-    TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
 }
 

@@ -20,25 +20,31 @@
 // overlapped almost nothing - 0.42 ms, the same as the two separate launches - and raising the consumer's priority
 // starved the producer (0.61 ms).  One wave per SIMD doing both in turn runs at the pipe's rate: 0.26 ms.
 //
-// The producer part also does the driver's fused commit (QuadCommit): it reads the reference trajectory through
-// sel[p] from the accepted candidate plane, writes it through to xref / uref and promotes the candidate gains (the
-// recursion overwrites the candidate gains of a step only after its chunk has been produced) - first sweep only,
-// a lambda retry finds them committed.
+// The producer part reads the reference trajectory through the driver's RefView (common.h): from candidate plane
+// ref_plane[p], no copy on accept; the actions it reads are written through to uref_out (first sweep only), the
+// array the rollout takes uref from.  The gains go to bank io.out_bank[p] of the double-buffered K / kff.
 //
 // Used by trajopt_ilqr_iterate for envs with identity cost features (structured cost), PROBLEM_MINOR gains group,
 // gains-only outputs; everything else takes the two-kernel path.
+#include <type_traits>
 #include "sys.h"
 
 namespace trajopt {
 
+#ifndef FUSED_DIAG
+#define FUSED_DIAG 0   // timing experiments only: 1 = no expansion arithmetic, 2 = no recursion (wrong results)
+#endif
 constexpr int kCH = 16;  // time steps per chunk: 16 steps x 4 problems = the 64 lanes of a wave
+// doubles per step image: 128 + 1 pad - the expansion's lanes (step, problem) write one element each of 16 different
+// step images per instruction, which at a stride of 128 doubles is a 16-way LDS bank conflict
+constexpr int kStep = 129;
 
 struct FusedArgs {
     trajopt_env_t env;
     trajopt_backward_io_t io;  // lmbda, dlmbda, dV, K, kff (the candidate gains), diverge, g_norm, active, cost_*
     trajopt_lambda_schedule_t sched;
-    const double *xref, *uref;  // current reference trajectory, PROBLEM_MINOR
-    QuadCommit cm;              // cm.sel == nullptr: nothing to commit
+    const double *xref, *uref;  // reference trajectory of the problems with ref_plane[p] < 0, PROBLEM_MINOR
+    RefView rv;                 // rv.ref_plane == nullptr: xref / uref for every problem
     size_t NP;
     int T, retry;
 };
@@ -46,9 +52,18 @@ struct FusedArgs {
 __device__ __forceinline__ double f4_mm(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ void f4_st(double x, double* base, unsigned off) {
-    *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off) = x;
+// Store through a buffer descriptor whose range is the array: a lane that must not store passes an offset beyond it
+// and the hardware drops the write.  The recursion's stores are therefore UNCONDITIONAL instructions - under a branch
+// hipcc's waitcnt pass cannot count them, and the wait for the prefetched inputs of the next chunk (older than these
+// stores in the in-order vmcnt queue) became a wait for every store of the chunk to be acknowledged.
+typedef unsigned f4_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t f4_rsrc(double* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
 }
+__device__ __forceinline__ void f4_st(double x, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f4_v2u, x), r, off, 0, 0);
+}
+constexpr unsigned kNoStore = 0xfffffff8u;  // beyond any array this kernel takes (byte offsets < 2^32 - 8 by the launcher's check)
 
 // LDS image of one time step for one wave: 128 doubles,
 //   [lane]       A operand: lane (r, q, c) = 16 r + 4 q + c holds A[r + N c] of problem q
@@ -59,10 +74,10 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
     constexpr int N = SYS::N, M = SYS::M;
     static_assert(M == 1 && N >= 2 && N <= 4, "four-problems-per-wave recursion: dx <= 4, du = 1");
     constexpr int KC = N + M;  // all tangent columns of [A | B] in one lane
-    __shared__ double tile_all[4][kCH][128];
+    __shared__ double tile_all[4][kCH * kStep];
 
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    double* tile = &tile_all[wave][0][0];
+    double* tile = &tile_all[wave][0];
     const size_t NP = a.NP;
     const int T = a.T;
     const int nch = (T + kCH - 1) / kCH;
@@ -79,8 +94,10 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
     const bool in_r = r < (unsigned)N, in_c = c < (unsigned)N, in_rc = in_r && in_c;
     const bool skip = !c_exists || (io.active && io.active[cp] == 0);
     const unsigned cc = in_c ? c : 0u, rr = in_r ? r : 0u, cp8 = (unsigned)(cp * 8);
-    const unsigned o_c0 = cc * np8 + cp8, o_z0 = cp8;  // K[c], kff of slice 0
-    const unsigned s_n = (unsigned)N * np8, s_1 = np8;
+    // gains: bank io.out_bank[cp] of the two interleaved per time step (trajopt_backward_io_t::out_bank)
+    const unsigned kmul = io.out_bank ? 2u : 1u, bank = c_exists ? (unsigned)gains_bank(io.out_bank, cp) : 0u;
+    const unsigned o_c0 = (bank * N + cc) * np8 + cp8, o_z0 = bank * np8 + cp8;  // K[c], kff of slice 0
+    const unsigned s_n = kmul * (unsigned)N * np8, s_1 = kmul * np8;
     const bool st_c = (N == 4) || in_c;
     const double eye = (r == c) ? 1.0 : 0.0;
     const double dg = (r == c && in_r) ? io.cost_gxx[r] : 0.0;
@@ -90,7 +107,7 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
     double lam = io.lmbda[cp];
     double dlam = (a.retry && io.dlmbda) ? io.dlmbda[cp] : 1.0;
     int csel = -1;
-    if (a.cm.sel && c_exists) csel = a.cm.sel[cp];
+    if (a.rv.ref_plane && c_exists) csel = a.rv.ref_plane[cp];
     int div = -1, retries = 0;
     double dV0 = 0.0, dV1 = 0.0, gmax = -INFINITY;
     bool frozen = skip;
@@ -102,12 +119,19 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
     const size_t pp = p_exists ? pp_raw : NP - 1;
     const bool p_livep = p_exists && !(io.active && io.active[pp] == 0);
     int p_sel = -1;
-    if (a.cm.sel && p_exists) p_sel = a.cm.sel[pp];
-    const double* p_xsrc = p_sel >= 0 ? a.cm.cand_state + (size_t)p_sel * En1 * NP : a.xref;
-    const double* p_usrc = p_sel >= 0 ? a.cm.cand_action + (size_t)p_sel * Em * NP : a.uref;
+    if (a.rv.ref_plane && p_exists) p_sel = a.rv.ref_plane[pp];
+    // the driver: time-blocked candidate plane ref_plane[p] (common.h); otherwise the dense xref / uref
+    const bool refp = a.rv.ref_plane != nullptr;
+    const double* p_xsrc = refp ? a.rv.cand_state + (size_t)(p_sel >= 0 ? p_sel : 0) * tb_plane(N, T + 1, NP) : a.xref;
+    const double* p_usrc = refp ? a.rv.cand_action + (size_t)(p_sel >= 0 ? p_sel : 0) * tb_plane(M, T, NP) : a.uref;
     const double sc = e.cost_times_dt ? e.dt : 1.0;
-    const double *c_Ksrc = a.cm.sel ? a.cm.cand_K : io.K, *c_kffsrc = a.cm.sel ? a.cm.cand_kff : io.kff;
     bool first_sweep = true;
+    const __amdgpu_buffer_rsrc_t rK = f4_rsrc(io.K, (unsigned)((size_t)kmul * N * M * T * NP * 8));
+    const __amdgpu_buffer_rsrc_t rkff = f4_rsrc(io.kff, (unsigned)((size_t)kmul * M * T * NP * 8));
+    // uref_out: dropped stores (offset beyond the range) for the lanes with nothing to write through
+    const bool through = a.rv.uref_out != nullptr && a.rv.xref_out != nullptr && refp && p_livep;
+    const __amdgpu_buffer_rsrc_t ruo = f4_rsrc(through ? a.rv.uref_out : io.kff, a.rv.uref_out ? (unsigned)((size_t)M * T * NP * 8) : 0u);
+    const __amdgpu_buffer_rsrc_t rxo = f4_rsrc(through ? a.rv.xref_out : io.kff, a.rv.xref_out ? (unsigned)((size_t)N * (T + 1) * NP * 8) : 0u);
 
     for (;;) {  // sweeps: one, plus one per lambda retry (ilqr.py:162-173)
         bool alive = !frozen;
@@ -120,8 +144,8 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
             // V[T] = w[T] diag(gxx), v[T] = cx[T] = w[T] gxx (y_T - g)
             const double wT = io.cost_w[T];
             const double VTerm = wT * dg;
-            const double* xs = csel >= 0 ? a.cm.cand_state + (size_t)csel * En1 * NP : a.xref;
-            const double xT = xs[((size_t)N * T + rr) * NP + cp];
+            const double xT = refp ? a.rv.cand_state[(size_t)(csel >= 0 ? csel : 0) * tb_plane(N, T + 1, NP) + tb_index(N, T, (int)rr, cp, NP)]
+                                   : a.xref[((size_t)N * T + rr) * NP + cp];
             double vterm = 0.0;
             if (wT != 0.0) {
                 const double y = ((e.periodic >> rr) & 1) ? wrap_angle(xT) : xT;
@@ -129,11 +153,17 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
                 vterm = h * (y - e.goal[rr]);
             }
             vR = in_r ? vterm : 0.0;
-            if (first_sweep && csel >= 0 && c == 0 && in_r) a.cm.xref[((size_t)N * T + rr) * NP + cp] = xT;
+            // x_T is not part of any chunk: written through here
+            if (first_sweep && a.rv.xref_out && refp && c == 0 && in_r && !skip) a.rv.xref_out[((size_t)N * T + rr) * NP + cp] = xT;
             VT = f4_mm(VTerm, eye, 0.0);
         }
 
-        auto step = [&](double inA, double inP, int t) {
+        // `valid` is false for the steps t < 0 of the last, partial chunk (TAIL): they run like the others - the same
+        // number of store instructions on every path is what lets the waitcnt pass count them - but store nothing
+        // and leave the sums alone.
+        auto step = [&](double inA, double inP, int t, auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
+            const bool valid = !TAIL || t >= 0;
             if (!p_live) inP = 0.0;
             if constexpr (N < 4) {
                 if (!in_rc) inA = 0.0;
@@ -161,13 +191,18 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
             }
             const bool bad = __builtin_amdgcn_class(q_reg, 0x27f);  // anything but +denormal | +normal (util.cpp:145)
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
-                if (alive && bad) { sdiv = t; snap0 = acc0; snap1 = acc1; alive = false; }
+                if (alive && bad && valid) { sdiv = t; snap0 = acc0; snap1 = acc1; alive = false; }
             }
             const double rho = rcp_nr(q_reg);
             const double kff = -rho * quF, KC_ = -rho * QxuC_r;
             const double Qk = QuuF * kff;
-            acc0 = fma(kff, quF, acc0);
-            acc1 = fma(kff, Qk, acc1);
+            if constexpr (TAIL) {
+                acc0 = valid ? fma(kff, quF, acc0) : acc0;
+                acc1 = valid ? fma(kff, Qk, acc1) : acc1;
+            } else {
+                acc0 = fma(kff, quF, acc0);  // util.cpp:154; acc1 is halved at the end of the sweep
+                acc1 = fma(kff, Qk, acc1);
+            }
             if constexpr (REG != 2) {
                 const double sig = rho * fma(QuuF, rho, -2.0);
                 vR = fma(sig * quF, QxuR, qxR);
@@ -178,17 +213,16 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
                 const double cross = KR * QxuC + QxuR * KC_;
                 VT = fma(QuuF, KR * KC_, fma(0.5, Qs, cross));
             }
-            if (alive) {
-                if (st_c) f4_st(KC_, io.K, os_c);
-                f4_st(kff, io.kff, os_z);
-                if constexpr (GN) {
-                    const double d = fabs(urF) + 1.0;
-                    double ri = __builtin_amdgcn_rcp(d);
-                    ri = fma(ri, fma(-d, ri, 1.0), ri);
-                    const double g = fabs(kff) * ri;
-                    gm = fmax(gm, g);
-                    gnan = fma(g, 0.0, gnan);
-                }
+            const bool st = alive && valid;
+            f4_st(KC_, rK, (st && st_c) ? os_c : kNoStore);
+            f4_st(kff, rkff, st ? os_z : kNoStore);
+            if constexpr (GN) {
+                const double d = fabs(urF) + 1.0;
+                double ri = __builtin_amdgcn_rcp(d);
+                ri = fma(ri, fma(-d, ri, 1.0), ri);
+                const double g = fabs(kff) * ri;
+                gm = st ? fmax(gm, g) : gm;
+                gnan = st ? fma(g, 0.0, gnan) : gnan;
             }
             os_c -= s_n;
             os_z -= s_1;
@@ -196,43 +230,51 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
 
         // Inputs of a chunk's expansion are fetched one chunk ahead (while the previous chunk's recursion runs): issued
         // at the top of a chunk, an HBM round trip per chunk was a quarter of the kernel.  Loads are unconditional, with
-        // clamped indices (a load under a branch makes hipcc's waitcnt pass drain the queue at the loop header); the
-        // candidate gains (cm.cand_K / cand_kff are the recursion's own output arrays: they still hold the previous
-        // iteration's for the steps not yet reached) are only used when this sweep commits.
-        double nx[N], nu[M], nul[M], ncK[N * M], nckff[M];
+        // clamped indices (a load under a branch makes hipcc's waitcnt pass drain the queue at the loop header).
+        double nx[N], nu[M], nul[M], nw;
         auto fetch = [&](int jn) {
             int t = T - 1 - kCH * jn - (int)ps;
             t = t < 0 ? 0 : t;
             const int tl = t >= 1 ? t - 1 : 0;
 #pragma unroll
-            for (int i = 0; i < N; ++i) nx[i] = p_xsrc[((size_t)N * t + i) * NP + pp];
+            for (int i = 0; i < N; ++i) nx[i] = p_xsrc[refp ? tb_index(N, t, i, pp, NP) : ((size_t)N * t + i) * NP + pp];
 #pragma unroll
             for (int k = 0; k < M; ++k) {
-                nu[k] = p_usrc[((size_t)M * t + k) * NP + pp];
-                nul[k] = p_usrc[((size_t)M * tl + k) * NP + pp];
-                nckff[k] = c_kffsrc[((size_t)M * t + k) * NP + pp];
+                nu[k] = p_usrc[refp ? tb_index(M, t, k, pp, NP) : ((size_t)M * t + k) * NP + pp];
+                nul[k] = p_usrc[refp ? tb_index(M, tl, k, pp, NP) : ((size_t)M * tl + k) * NP + pp];
             }
-#pragma unroll
-            for (int k = 0; k < N * M; ++k) ncK[k] = c_Ksrc[((size_t)N * M * t + k) * NP + pp];
+            nw = io.cost_w[t];
         };
         fetch(0);
+        // as many (dropped) stores behind the first fetch as a chunk's recursion puts behind every later one: the waitcnt
+        // pass merges the loop's two entries, and with no stores on this one it waits for ALL but the newest few
+        // operations at the top of a chunk - i.e. for the previous chunk's stores to be acknowledged
+#pragma unroll
+        for (int k = 0; k < kCH; ++k) { f4_st(0.0, rK, kNoStore); f4_st(0.0, rkff, kNoStore); }
+        f4_st(0.0, ruo, kNoStore);
+#pragma unroll
+        for (int i = 0; i < N; ++i) f4_st(0.0, rxo, kNoStore);
+        unsigned long long cyc_prod = 0, cyc_cons = 0, t0_ = 0;
         for (int j = 0; j < nch; ++j) {
+            if (FUSED_DIAG == 3) t0_ = __builtin_amdgcn_s_memtime();
             const int tc = T - 1 - kCH * j;  // newest step of the chunk
             // ---- produce: expansion of steps tc .. tc - 15 for the wave's four problems ----
             {
                 const int t = tc - (int)ps;
-                const bool commit = first_sweep && p_sel >= 0;
-                double x[N], u[M], ul[M], cK[N * M], ckff[M];
+                double x[N], u[M], ul[M];
 #pragma unroll
                 for (int i = 0; i < N; ++i) x[i] = nx[i];
 #pragma unroll
-                for (int k = 0; k < M; ++k) { u[k] = nu[k]; ul[k] = (e.slew_rate && t >= 1) ? nul[k] : 0.0; ckff[k] = nckff[k]; }
+                for (int k = 0; k < M; ++k) { u[k] = nu[k]; ul[k] = (e.slew_rate && t >= 1) ? nul[k] : 0.0; }
+                const double w = nw;
+                // what was just read, written through for the rollout (unconditional instructions: see f4_st)
+                const bool wt = through && first_sweep && t >= 0;
+                f4_st(u[0], ruo, wt ? (unsigned)(((size_t)t * NP + pp) * 8) : kNoStore);
 #pragma unroll
-                for (int k = 0; k < N * M; ++k) cK[k] = ncK[k];
-                fetch(j + 1 < nch ? j + 1 : j);
-                if (t >= 0 && (p_livep || commit)) {
-                    if (p_livep) {
-                        double* Lw = tile + ps * 128;
+                for (int i = 0; i < N; ++i) f4_st(x[i], rxo, wt ? (unsigned)((((size_t)N * t + i) * NP + pp) * 8) : kNoStore);
+                if (t >= 0 && p_livep) {
+                    if (FUSED_DIAG != 1) {
+                        double* Lw = tile + ps * kStep;
                         double J[N][KC];
                         SYS::template jacobian_cols<KC>(e, x, u, 0, J);
 #pragma unroll
@@ -242,7 +284,6 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
 #pragma unroll
                         for (int i = 0; i < N; ++i) Lw[64 + 4 * pq + i] = J[i][N];
                         // cost expansion (objects.py:72-78), closed form for identity features
-                        const double w = io.cost_w[t];
 #pragma unroll
                         for (int i = 0; i < N; ++i) {
                             double g = 0.0;
@@ -258,38 +299,37 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
                         Lw[64 + 32 + 4 * pq + 1] = u[0];
                         Lw[64 + 32 + 4 * pq + 2] = w;
                     }
-                    if (commit) {
-#pragma unroll
-                        for (int i = 0; i < N; ++i) a.cm.xref[((size_t)N * t + i) * NP + pp] = x[i];
-#pragma unroll
-                        for (int k = 0; k < M; ++k) {
-                            a.cm.uref[((size_t)M * t + k) * NP + pp] = u[k];
-                            a.cm.kff[((size_t)M * t + k) * NP + pp] = ckff[k];
-                        }
-#pragma unroll
-                        for (int k = 0; k < N * M; ++k) a.cm.K[((size_t)N * M * t + k) * NP + pp] = cK[k];
-                    }
                 }
             }
+            // the next chunk's inputs: issued here, not before the expansion - there every register is taken and hipcc
+            // parks the load destinations in AGPRs at once, i.e. waits for the loads it has just issued
+            fetch(j + 1 < nch ? j + 1 : j);
+            if (FUSED_DIAG == 3) { __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); cyc_prod += t1_ - t0_; t0_ = t1_; }
             // ---- consume: the recursion over the chunk (the wave's own LDS writes above are ordered before these
             // reads by its in-order LDS queue; the fence keeps the compiler from moving them) ----
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            {
+            auto consume = [&](auto tail_c) {
                 double inA = tile[lane], inP = tile[64 + lane];
 #pragma unroll
                 for (int s = 0; s < kCH; ++s) {
                     double nA = 0.0, nP = 0.0;
-                    if (s + 1 < kCH) { nA = tile[(s + 1) * 128 + lane]; nP = tile[(s + 1) * 128 + 64 + lane]; }
-                    if (tc - s >= 0) step(inA, inP, tc - s);
+                    if (s + 1 < kCH) { nA = tile[(s + 1) * kStep + lane]; nP = tile[(s + 1) * kStep + 64 + lane]; }
+                    step(inA, inP, tc - s, tail_c);
                     inA = nA; inP = nP;
                 }
+            };
+            if (FUSED_DIAG != 2) {
+                if (tc >= kCH - 1) consume(std::false_type{});
+                else consume(std::true_type{});
             }
+            if (FUSED_DIAG == 3) { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); cyc_cons += t2_ - t0_; }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
 
         bool again = false;
+        if (FUSED_DIAG == 3) { acc0 = (double)cyc_prod; acc1 = 2.0 * (double)cyc_cons; sdiv = -1; }
         if (!frozen) {
             div = sdiv;
             dV0 = sdiv >= 0 ? snap0 : acc0;
@@ -298,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
             if (a.retry && sdiv >= 0) {  // ilqr.py:166-169
                 dlam = fmax(dlam * a.sched.mult_lmbda, a.sched.mult_lmbda);
                 lam = fmax(lam * dlam, a.sched.min_lmbda);
-                again = (lam <= a.sched.max_lmbda) && (lam < 1e300);
+                again = (lam <= a.sched.max_lmbda) && (lam < 1e300) && FUSED_DIAG == 0;
             }
         }
         frozen = frozen || !again;
@@ -315,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
             if (io.dlmbda) io.dlmbda[cp] = dlam;
         }
         if constexpr (GN) {
-            if (io.g_norm) io.g_norm[cp] = gmax;
+            if (io.g_norm) io.g_norm[cp] = FUSED_DIAG == 4 ? (double)retries : gmax;
         }
     }
 }
@@ -360,11 +400,11 @@ bool fused_qb4_supported(const trajopt_env_t* env, int T, int64_t NP) {
 // gains-only outputs; A, B, cx, cu, Cxx, Cuu, Cxu are not used.
 int launch_fused_qb4(const trajopt_env_t* env, const trajopt_backward_io_t& io, int reg, int T, int64_t NP, int retry,
                      const trajopt_lambda_schedule_t& sched, const double* xref, const double* uref,
-                     const QuadCommit* cm, hipStream_t st) {
+                     const RefView* rv, hipStream_t st) {
     if (!fused_qb4_supported(env, T, NP) || !io.cost_w) return TRAJOPT_ERR_UNSUPPORTED;
     FusedLaunch L;
     L.a.env = *env; L.a.io = io; L.a.sched = sched; L.a.xref = xref; L.a.uref = uref;
-    L.a.cm = cm ? *cm : QuadCommit{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    L.a.rv = rv ? *rv : RefView{nullptr, nullptr, nullptr, nullptr, nullptr};
     L.a.NP = (size_t)NP; L.a.T = T; L.a.retry = retry;
     L.reg = reg; L.gn = io.uref != nullptr && io.g_norm != nullptr; L.done = false; L.st = st;
     if (!dispatch_model(*env, L) || !L.done) return TRAJOPT_ERR_UNSUPPORTED;

@@ -23,12 +23,12 @@ struct QuadArgs {
     double *A, *B, *c, *Cxx, *cx, *Cuu, *cu, *Cxu;
     size_t NP;
     int T, convention;
-    // Optional fused commit of the previous iteration's line search (driver only; ilqr.py:210-217): when `sel`
-    // is non-NULL and sel[p] >= 0 the reference trajectory is READ from candidate plane sel[p] and written
-    // through to xref/uref (which alias c_xref/c_uref), and the candidate gains are promoted to K/kff.
-    const int32_t* sel;
-    const double *cand_state, *cand_action, *cand_K, *cand_kff;
-    double *c_xref, *c_uref, *c_K, *c_kff;
+    // Driver only (no copy on accept, RefView in common.h): with `ref_plane` non-NULL problem p reads its reference
+    // trajectory from the time-blocked candidate plane ref_plane[p] and writes what it read through to xref_out /
+    // uref_out - the dense arrays the backward pass (gradient norm, ilqr.py:176) and the rollout take it from.
+    const int32_t* ref_plane;
+    const double *cand_state, *cand_action;
+    double *xref_out, *uref_out;
 };
 
 template <bool MINOR>
@@ -48,62 +48,39 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
     const int t = (int)blockIdx.y, chunk = (int)blockIdx.z;
     if (p >= NP) return;
     const size_t En1 = (size_t)n * (T + 1), Em = (size_t)m * T;
-    // a problem that was accepted AND stopped in the previous iteration is inactive now but still has to be
-    // committed, so the activity test comes after the commit
-    const bool live = !(a.active && a.active[p] == 0);
-    if (!live && !(a.sel && chunk == 0 && a.sel[p] >= 0)) return;
+    if (a.active && a.active[p] == 0) return;
 
-    const double* xsrc = a.xref;
-    const double* usrc = a.uref;
-    bool commit = false;
-    if (a.sel) {
-        const int k = a.sel[p];
-        if (k >= 0) {
-            xsrc = a.cand_state + (size_t)k * En1 * NP;
-            usrc = a.cand_action + (size_t)k * Em * NP;
-            commit = (chunk == 0);
+    double x[N], u[M], ul[M];
+    bool through = false;
+    if (a.ref_plane) {   // the driver: time-blocked candidate plane ref_plane[p] (common.h)
+        const int k = a.ref_plane[p] >= 0 ? a.ref_plane[p] : 0;
+        const double* xs = a.cand_state + (size_t)k * tb_plane(n, T + 1, NP);
+        const double* us = a.cand_action + (size_t)k * tb_plane(m, T, NP);
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = (i < n) ? xs[tb_index(n, t, i, p, NP)] : 0.0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            u[j] = (j < m && t < T) ? us[tb_index(m, t, j, p, NP)] : 0.0;
+            ul[j] = (j < m && t >= 1) ? us[tb_index(m, t - 1, j, p, NP)] : 0.0;
+        }
+        through = (chunk == 0 && a.uref_out != nullptr && a.xref_out != nullptr);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = (i < n) ? a.xref[qi<MINOR>((size_t)n * t + i, En1, p, NP)] : 0.0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            // _u = hstack(u, 0): the pad is u_T and, through Python's negative index, also u_last at t = 0
+            u[j] = (j < m && t < T) ? a.uref[qi<MINOR>((size_t)m * t + j, Em, p, NP)] : 0.0;
+            ul[j] = (j < m && t >= 1) ? a.uref[qi<MINOR>((size_t)m * (t - 1) + j, Em, p, NP)] : 0.0;
         }
     }
-    double x[N], u[M], ul[M];
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = (i < n) ? xsrc[qi<MINOR>((size_t)n * t + i, En1, p, NP)] : 0.0;
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-        // _u = hstack(u, 0): the pad is u_T and, through Python's negative index, also u_last at t = 0
-        u[j] = (j < m && t < T) ? usrc[qi<MINOR>((size_t)m * t + j, Em, p, NP)] : 0.0;
-        ul[j] = (j < m && t >= 1) ? usrc[qi<MINOR>((size_t)m * (t - 1) + j, Em, p, NP)] : 0.0;
-    }
-    // Fused commit: its loads are issued here, with the trajectory loads; its stores come last (after the expansion
-    // has been computed and stored), so that nothing of the commit sits between the loads and the arithmetic.
-    double cK[N * M], ckff[M];
-    const size_t Enm_ = (size_t)n * m * T;
-    if (commit && t < T) {
-#pragma unroll
-        for (int j = 0; j < M; ++j)
-            if (j < m) ckff[j] = a.cand_kff[qi<OMINOR>((size_t)m * t + j, Em, p, NP)];
-#pragma unroll
-        for (int k = 0; k < N * M; ++k)
-            if (k < n * m) cK[k] = a.cand_K[qi<OMINOR>((size_t)n * m * t + k, Enm_, p, NP)];
-    }
-    auto commit_stores = [&]() {
+    if (through) {
 #pragma unroll
         for (int i = 0; i < N; ++i)
-            if (i < n) a.c_xref[qi<MINOR>((size_t)n * t + i, En1, p, NP)] = x[i];
-        if (t < T) {
+            if (i < n) a.xref_out[qi<MINOR>((size_t)n * t + i, En1, p, NP)] = x[i];
 #pragma unroll
-            for (int j = 0; j < M; ++j)
-                if (j < m) {
-                    a.c_uref[qi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
-                    a.c_kff[qi<OMINOR>((size_t)m * t + j, Em, p, NP)] = ckff[j];
-                }
-#pragma unroll
-            for (int k = 0; k < N * M; ++k)
-                if (k < n * m) a.c_K[qi<OMINOR>((size_t)n * m * t + k, Enm_, p, NP)] = cK[k];
-        }
-    };
-    if (!live) {
-        if (commit) commit_stores();
-        return;
+        for (int j = 0; j < M; ++j)
+            if (j < m && t < T) a.uref_out[qi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
     }
 
     if (t < T) {  // dynamics Jacobian columns of this chunk
@@ -170,7 +147,6 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
                 }
             }
     }
-    if (commit) commit_stores();
 }
 
 // Riccati convention fix-up (riccati/objects.py:60-65,107-108), one thread per (problem, step):
@@ -281,17 +257,14 @@ struct QuadLaunch {
 int launch_quadratize(const trajopt_env_t* env, int T, int64_t NP, int layout, int convention, const double* xref,
                       const double* uref, const double* weighting, const int32_t* active, double* A, double* B,
                       double* c, double* Cxx, double* cx, double* Cuu, double* cu, double* Cxu, hipStream_t st,
-                      const QuadCommit* cm, int out_layout) {
+                      const RefView* rv, int out_layout) {
     QuadLaunch L;
     L.a.env = *env;
-    L.a.sel = nullptr;
-    L.a.cand_state = L.a.cand_action = L.a.cand_K = L.a.cand_kff = nullptr;
-    L.a.c_xref = L.a.c_uref = L.a.c_K = L.a.c_kff = nullptr;
-    if (cm) {
+    L.a.ref_plane = nullptr; L.a.cand_state = L.a.cand_action = nullptr; L.a.xref_out = L.a.uref_out = nullptr;
+    if (rv && rv->ref_plane) {
         if (layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
-        L.a.sel = cm->sel; L.a.cand_state = cm->cand_state; L.a.cand_action = cm->cand_action;
-        L.a.cand_K = cm->cand_K; L.a.cand_kff = cm->cand_kff;
-        L.a.c_xref = cm->xref; L.a.c_uref = cm->uref; L.a.c_K = cm->K; L.a.c_kff = cm->kff;
+        L.a.ref_plane = rv->ref_plane; L.a.cand_state = rv->cand_state; L.a.cand_action = rv->cand_action;
+        L.a.xref_out = rv->xref_out; L.a.uref_out = rv->uref_out;
     }
     L.a.xref = xref; L.a.uref = uref; L.a.weighting = weighting; L.a.active = active;
     L.a.A = A; L.a.B = B; L.a.c = c; L.a.Cxx = Cxx; L.a.cx = cx; L.a.Cuu = Cuu; L.a.cu = cu; L.a.Cxu = Cxu;

@@ -9,6 +9,7 @@
 // candidate state/action/cost is one coalesced row per wave, and the alphas of a problem re-read the
 // same gain rows from L2.  The inputs of step t+1 are fetched while step t integrates.
 #include <cstddef>
+#include <type_traits>
 #include "sys.h"
 
 namespace trajopt {
@@ -27,11 +28,58 @@ struct RolloutArgs {
     int alpha_begin;
     const int32_t* plist;
     const int32_t* pcount;
+    // Driver only (RolloutBanks in common.h; NULL / 0 otherwise): state / action are the driver's TIME-BLOCKED
+    // candidate planes, `planes` per bank; problem p writes bank wbank[p] (bank 0 without wbank) and reads the gains
+    // from that bank of the double-buffered K / kff (layout: trajopt_backward_io_t::out_bank).
+    const int32_t* wbank;
+    int planes;
 };
+
+// index into the gains K / kff, which hold kmul = 2 banks when the driver double-buffers them
+template <bool KMINOR>
+__device__ __forceinline__ size_t gk(size_t eps, size_t slices, int t, size_t e, size_t p, size_t NP, int kmul, int bank) {
+    return KMINOR ? (eps * (size_t)(kmul * t + bank) + e) * NP + p
+                  : ((size_t)bank * NP + p) * eps * slices + eps * (size_t)t + e;
+}
 
 template <bool MINOR>
 __device__ __forceinline__ size_t gi(size_t e_total, size_t E_total, size_t p, size_t NP) {
     return MINOR ? e_total * NP + p : p * E_total + e_total;
+}
+
+// Staging of a wave's candidate stores for the time-blocked planes (TB; common.h).  A lane produces one double per
+// element and step, but a plane wants the 8 steps of a block next to each other: written as they come, every store
+// instruction would touch 32 cache lines with 16 bytes each (measured: the rollout took twice as long).  So the wave
+// collects a block - 8 steps x 64 lanes per element - in LDS and writes it out transposed: store k of a row covers
+// the lane-problems 8 k .. 8 k + 7 with their 8 steps each, 512 contiguous bytes when the wave's problems are
+// neighbours in one bank (and whole 64-byte runs otherwise).  Rows are padded to 68 doubles: the transposed read
+// (lane = 8 problem + step -> address 68 step + problem) is then free of bank conflicts per half-wave.
+constexpr int kStageLd = 68;
+template <int ROWS>
+struct TbStage {
+    double v[ROWS * kTB * kStageLd];
+    unsigned long long bx[64], bu[64];   // per lane-problem: element offset of (block 0, row 0) in state / action
+};
+// rows [row0, row0 + rows) of the stage = block `blk` of `base` (a plane set with `rows` rows per block)
+// Every store is an unconditional instruction (a store under a branch cannot be counted by hipcc's waitcnt pass, which
+// then makes the loads behind it wait for all of them): lanes without a result of their own - beyond the batch, or a
+// stopped problem - write what they computed along with the others, into planes nobody reads (see the kernel).
+template <int ROWS>
+__device__ __forceinline__ void tb_flush(const TbStage<ROWS>& sg, const unsigned long long* off, double* base, int row0,
+                                         int rows, int blk, size_t NP, unsigned lane) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned step = lane & (kTB - 1), pj = lane >> 3;
+    const size_t rstride = NP * kTB;
+    double* dst0 = base + ((size_t)blk * rows) * rstride + step;
+#pragma unroll
+    for (int k = 0; k < 64 / kTB; ++k) {
+        const unsigned prob = (unsigned)k * (64 / kTB) + pj;
+        double* d = dst0 + off[prob];
+        for (int r = 0; r < rows; ++r) d[(size_t)r * rstride] = sg.v[((row0 + r) * kTB + step) * kStageLd + prob];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // MINOR: layout of x0 / xref / uref / candidates;  KMINOR: layout of the gains K, kff (the batched driver keeps
@@ -39,10 +87,12 @@ __device__ __forceinline__ size_t gi(size_t e_total, size_t E_total, size_t p, s
 // FAST: the batched driver's call - state and action planes given, no per-step cost plane, plain cost (no slew rate,
 // no angle wrapping, no dt scaling) - with the stores unconditional: a store under a (wave-uniform) `if (pointer)` makes the waitcnt pass wait for EVERY outstanding
 // memory operation (vmcnt(0)) before the prefetched gains are used, i.e. for this step's stores to be acknowledged.
-template <class SYS, bool MINOR, bool KMINOR, bool FAST>
+// TB: state / action are the driver's time-blocked candidate planes, written through the LDS stage above.
+template <class SYS, bool MINOR, bool KMINOR, bool FAST, bool TB>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     constexpr int N = SYS::N, M = SYS::M;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned lane = threadIdx.x;
     const size_t NP = a.NP;
     size_t p;
     int ai;
@@ -63,6 +113,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     // back from LDS lives in VGPRs (plentiful here); only the fields a model uses survive as registers.  The LQR
     // env indexes its matrices with run-time dimensions and keeps the kernel-argument copy.
     __shared__ trajopt_env_t s_env;
+    __shared__ TbStage<TB ? N + M : 1> s_stage;
     if constexpr (SYS::kStatic) {
         // everything but the LQR matrices: [0, lin_A) and [phys, end) - 64 doubles, one pass of the wave
         constexpr unsigned kHead = offsetof(trajopt_env_t, lin_A) / sizeof(double);
@@ -76,7 +127,17 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         }
         __syncthreads();
     }
-    if (idle || (a.active && a.active[p] == 0)) return;
+    // A lane with nothing to do (beyond the batch, or a stopped problem) leaves at once - except under TB, where the
+    // whole wave writes the staged blocks out together: there it runs along on its own problem's data (beyond the
+    // batch: as a duplicate of the first lane of the grid, same values to the same addresses) and writes its candidates
+    // like the others - into the bank a stopped problem never reads again - but not its return; a wave without any
+    // live lane still leaves as a whole.
+    const bool live = !idle && !(a.active && a.active[p] == 0);
+    if constexpr (TB) {
+        if (__builtin_amdgcn_ballot_w64(live) == 0) return;
+    } else {
+        if (!live) return;
+    }
     trajopt_env_t ev;
     if constexpr (SYS::kStatic) {
         ev = s_env;
@@ -96,10 +157,29 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     const int n = SYS::n(e), m = SYS::m(e), T = a.T;
     const double alpha = a.alphas[ai];
     const size_t En1 = (size_t)n * (T + 1), En = (size_t)n * T, Em = (size_t)m * T, Enm = (size_t)n * m * T;
-    // candidate planes: alpha slowest
-    double* st = a.state ? a.state + (size_t)ai * En1 * NP : nullptr;
-    double* ac = a.action ? a.action + (size_t)ai * Em * NP : nullptr;
+    const int kmul = a.wbank ? 2 : 1, bank = a.wbank ? (a.wbank[p] & 1) : 0;
+    // candidate planes: alpha slowest, inside the problem's bank
+    const size_t plane = (size_t)bank * a.planes + ai;
+    double* st = (!TB && a.state) ? a.state + plane * En1 * NP : nullptr;
+    double* ac = (!TB && a.action) ? a.action + plane * Em * NP : nullptr;
     double* co = a.cost ? a.cost + (size_t)ai * (size_t)(T + 1) * NP : nullptr;
+    if constexpr (TB) {
+        s_stage.bx[lane] = plane * tb_plane(n, T + 1, NP) + p * kTB;
+        s_stage.bu[lane] = plane * tb_plane(m, T, NP) + p * kTB;
+    }
+    // TB: element i of state slice s / element j of action slice t goes to the stage.  Both blocks b = t / 8 are
+    // written out together after the step with t % 8 == 7 - BEFORE that step's new state, slice 8 b + 8, which is slot
+    // 0 of the next block, is put - and whatever the last, partial blocks hold after the last step.
+    auto put_x = [&](int s, int i, double v) { s_stage.v[(i * kTB + (s & (kTB - 1))) * kStageLd + lane] = v; };
+    auto put_u = [&](int t, int j, double v) { s_stage.v[((n + j) * kTB + (t & (kTB - 1))) * kStageLd + lane] = v; };
+    auto flush_block = [&](int b) {
+        tb_flush(s_stage, s_stage.bx, a.state, 0, n, b, NP, lane);
+        tb_flush(s_stage, s_stage.bu, a.action, n, m, b, NP, lane);
+    };
+    auto flush_tail = [&]() {   // slices 8 (T / 8) .. T of the states, .. T - 1 of the actions
+        tb_flush(s_stage, s_stage.bx, a.state, 0, n, T / kTB, NP, lane);
+        if (T % kTB != 0) tb_flush(s_stage, s_stage.bu, a.action, n, m, T / kTB, NP, lane);
+    };
 
     double x[N], xr[N], ur[M], kf[M], Kt[M * N];
     bool fin = true;
@@ -109,7 +189,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         if (i < n) {
             x[i] = a.x0[gi<MINOR>(i, n, p, NP)];
             fin = fin && (x[i] < 1e8);
-            if (FAST || a.state) st[gi<MINOR>(i, En1, p, NP)] = x[i];
+            if constexpr (TB) put_x(0, i, x[i]);
+            else if (FAST || a.state) st[gi<MINOR>(i, En1, p, NP)] = x[i];
         }
     if constexpr (FAST) {
         // The driver's variant.  Addresses are a wave-uniform slice pointer per array (advanced with scalar adds) plus
@@ -125,12 +206,13 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
 #pragma unroll
         for (int j = 0; j < M; ++j) {
             ou[j] = (unsigned)j * np8 + p8;
-            okf[j] = KMINOR ? ou[j] : (unsigned)((p * Em + j) * 8);
+            okf[j] = KMINOR ? (unsigned)(bank * M + j) * np8 + p8 : (unsigned)((((size_t)bank * NP + p) * Em + j) * 8);
         }
 #pragma unroll
-        for (int k = 0; k < M * N; ++k) oK[k] = KMINOR ? (unsigned)k * np8 + p8 : (unsigned)((p * Enm + k) * 8);
-        const size_t sx = (size_t)N * np8, su = (size_t)M * np8, skf = KMINOR ? su : (size_t)M * 8,
-                     sK = KMINOR ? (size_t)N * M * np8 : (size_t)N * M * 8;
+        for (int k = 0; k < M * N; ++k)
+            oK[k] = KMINOR ? (unsigned)(bank * M * N + k) * np8 + p8 : (unsigned)((((size_t)bank * NP + p) * Enm + k) * 8);
+        const size_t sx = (size_t)N * np8, su = (size_t)M * np8, skf = KMINOR ? kmul * su : (size_t)M * 8,
+                     sK = KMINOR ? (size_t)kmul * N * M * np8 : (size_t)N * M * 8;
         const char *pxr = reinterpret_cast<const char*>(a.xref), *pur = reinterpret_cast<const char*>(a.uref),
                    *pK = reinterpret_cast<const char*>(a.K), *pkf = reinterpret_cast<const char*>(a.kff),
                    *pw = reinterpret_cast<const char*>(a.weighting);
@@ -148,12 +230,18 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         };
         double* sp[N];
         double* ap[M];
+        if constexpr (!TB) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) sp[i] = st + ((size_t)i * NP + p);
+            for (int i = 0; i < N; ++i) sp[i] = st + ((size_t)i * NP + p);
 #pragma unroll
-        for (int j = 0; j < M; ++j) ap[j] = ac + ((size_t)j * NP + p);
+            for (int j = 0; j < M; ++j) ap[j] = ac + ((size_t)j * NP + p);
+        }
         const size_t dsx = (size_t)N * NP, dsu = (size_t)M * NP;
-        auto step = [&](const In& s) {
+        int t = 0;
+        // put_next: the new state belongs to the block being filled (false only for the last step of a block, whose
+        // new state the caller puts after the block has been written out)
+        auto step = [&](const In& s, auto put_next_c) {
+            constexpr bool put_next = decltype(put_next_c)::value;
             double u[M];  // u = clip(uref + alpha kff + K (x - xref))    objects.py:137-139, ilqr.py:97
 #pragma unroll
             for (int j = 0; j < M; ++j) {
@@ -164,34 +252,70 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
             }
             total += env_cost_plain<N, M>(e, x, u, s.w);  // ilqr.py:98 passes u_last = u_t
 #pragma unroll
-            for (int j = 0; j < M; ++j) { *ap[j] = u[j]; ap[j] += dsu; }
+            for (int j = 0; j < M; ++j) {
+                if constexpr (TB) put_u(t, j, u[j]);
+                else { *ap[j] = u[j]; ap[j] += dsu; }
+            }
             double xn[N];
             SYS::dynamics_clipped(e, x, u, xn);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 x[i] = xn[i];
                 fin = fin && (x[i] < 1e8);
-                sp[i] += dsx;
-                *sp[i] = x[i];
+                if constexpr (TB) { if constexpr (put_next) put_x(t + 1, i, x[i]); }
+                else { sp[i] += dsx; *sp[i] = x[i]; }
             }
         };
         In sa, sb;
         load(sa);
-        int t = 0;
-        while (t < T) {
-            load(sb);
-            step(sa);
-            if (++t >= T) break;
-            load(sa);
-            step(sb);
-            ++t;
+        if constexpr (TB) {
+            // Whole blocks: 8 steps, then both blocks go out - unconditional code in a loop with one entry state.  As
+            // many stores are put behind the first load as a block's write-out puts behind every later one (block 0 as
+            // it stands, written again when it is complete): the waitcnt pass merges the loop's two entries, and with
+            // no stores on the first it would make every block wait for ALL but the newest loads, i.e. for its own
+            // write-out to be acknowledged.
+            flush_block(0);
+            const int nblk = T / kTB;
+            for (int b = 0; b < nblk; ++b) {
+#pragma unroll
+                for (int k = 0; k < kTB / 2; ++k) {
+                    load(sb);
+                    step(sa, std::true_type{});
+                    ++t;
+                    load(sa);
+                    if (k + 1 < kTB / 2) step(sb, std::true_type{});
+                    else step(sb, std::false_type{});
+                    ++t;
+                }
+                flush_block(b);
+#pragma unroll
+                for (int i = 0; i < N; ++i) put_x(t, i, x[i]);   // slice 8 b + 8 = slot 0 of the next block
+            }
+            while (t < T) {   // the last, partial block: fewer than 8 steps
+                load(sb);
+                step(sa, std::true_type{});
+                ++t;
+                sa = sb;
+            }
+            flush_tail();
+        } else {
+            while (t < T) {
+                load(sb);
+                step(sa, std::true_type{});
+                if (++t >= T) break;
+                load(sa);
+                step(sb, std::true_type{});
+                ++t;
+            }
         }
         double zero[M];
 #pragma unroll
         for (int j = 0; j < M; ++j) zero[j] = 0.0;
         total += env_cost_plain<N, M>(e, x, zero, a.weighting[T]);  // ilqr.py:101
-        if (a.ret) a.ret[(size_t)ai * NP + p] = total;
-        if (a.finite) a.finite[(size_t)ai * NP + p] = fin ? 1 : 0;
+        if (live) {
+            if (a.ret) a.ret[(size_t)ai * NP + p] = total;
+            if (a.finite) a.finite[(size_t)ai * NP + p] = fin ? 1 : 0;
+        }
         return;
     }
     auto load = [&](int t) {
@@ -202,11 +326,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         for (int j = 0; j < M; ++j)
             if (j < m) {
                 ur[j] = a.uref[gi<MINOR>((size_t)m * t + j, Em, p, NP)];
-                kf[j] = a.kff[gi<KMINOR>((size_t)m * t + j, Em, p, NP)];
+                kf[j] = a.kff[gk<KMINOR>(m, T, t, j, p, NP, kmul, bank)];
             }
 #pragma unroll
         for (int k = 0; k < M * N; ++k)
-            if (k < n * m) Kt[k] = a.K[gi<KMINOR>((size_t)n * m * t + k, Enm, p, NP)];
+            if (k < n * m) Kt[k] = a.K[gk<KMINOR>((size_t)n * m, T, t, k, p, NP, kmul, bank)];
     };
     if (T > 0) load(0);
     double w = a.weighting[0];
@@ -229,21 +353,30 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         const double c = env_cost<N, M>(e, x, u, u, wt, n, m);  // ilqr.py:98 passes u_last = u_t
         total += c;
         if (a.cost) co[gi<MINOR>(t, T + 1, p, NP)] = c;
-        if (a.action) {
+        if constexpr (TB) {
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if (j < m) put_u(t, j, u[j]);
+        } else if (a.action) {
 #pragma unroll
             for (int j = 0; j < M; ++j)
                 if (j < m) ac[gi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
         }
         double xn[N];
         SYS::dynamics_clipped(e, x, u, xn);  // u is clipped above
+        if constexpr (TB) {
+            if ((t & (kTB - 1)) == kTB - 1) flush_block(t / kTB);
+        }
 #pragma unroll
         for (int i = 0; i < N; ++i)
             if (i < n) {
                 x[i] = xn[i];
                 fin = fin && (x[i] < 1e8);
-                if (a.state) st[gi<MINOR>((size_t)n * (t + 1) + i, En1, p, NP)] = x[i];
+                if constexpr (TB) put_x(t + 1, i, x[i]);
+                else if (a.state) st[gi<MINOR>((size_t)n * (t + 1) + i, En1, p, NP)] = x[i];
             }
     }
+    if constexpr (TB) flush_tail();
     {
         double zero[M];
 #pragma unroll
@@ -252,8 +385,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         total += c;
         if (a.cost) co[gi<MINOR>(T, T + 1, p, NP)] = c;
     }
-    if (a.ret) a.ret[(size_t)ai * NP + p] = total;
-    if (a.finite) a.finite[(size_t)ai * NP + p] = fin ? 1 : 0;
+    if (live) {
+        if (a.ret) a.ret[(size_t)ai * NP + p] = total;
+        if (a.finite) a.finite[(size_t)ai * NP + p] = fin ? 1 : 0;
+    }
 }
 
 struct StepArgs {
@@ -289,6 +424,7 @@ __global__ void env_step_kernel(StepArgs s) {
 
 struct RolloutLaunch {
     RolloutArgs a;
+    bool tb;   // time-blocked candidate planes (the driver's call)
     int layout, k_layout;
     hipStream_t st;
     template <class SYS>
@@ -297,21 +433,25 @@ struct RolloutLaunch {
         const dim3 grid((unsigned)((total + 63) / 64)), block(64);
         const bool mi = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR, kmi = k_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
         // (FAST addresses the gains with 32-bit per-lane byte offsets)
-        const double kbytes = kmi ? (double)SYS::N * SYS::M * (double)a.NP * 8.0
-                                  : (double)a.NP * SYS::N * SYS::M * (double)a.T * 8.0;
+        const double kbytes = (a.wbank ? 2.0 : 1.0) * (kmi ? (double)SYS::N * SYS::M * (double)a.NP * 8.0
+                                                           : (double)a.NP * SYS::N * SYS::M * (double)a.T * 8.0);
         const bool fast = SYS::kStatic && a.state && a.action && !a.cost && !a.env.slew_rate && a.env.periodic == 0 &&
                           !a.env.cost_times_dt && a.env.nb_features == 0 && a.T > 0 && kbytes + (double)a.NP * 8.0 < 4294967296.0;
         if constexpr (SYS::kStatic) {
             if (mi && fast) {
-                if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true>), grid, block, 0, st, a);
+                if (tb && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, true>), grid, block, 0, st, a);
+                else if (tb) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, true>), grid, block, 0, st, a);
+                else if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, false>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, false>), grid, block, 0, st, a);
                 return;
             }
         }
-        if (mi && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false>), grid, block, 0, st, a);
-        else if (mi) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, false>), grid, block, 0, st, a);
-        else if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, false, true, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((rollout_kernel<SYS, false, false, false>), grid, block, 0, st, a);
+        if (tb && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false, true>), grid, block, 0, st, a);   // (tb: mi)
+        else if (tb) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, false, true>), grid, block, 0, st, a);
+        else if (mi && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false, false>), grid, block, 0, st, a);
+        else if (mi) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, false, false>), grid, block, 0, st, a);
+        else if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, false, true, false, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((rollout_kernel<SYS, false, false, false, false>), grid, block, 0, st, a);
     }
 };
 
@@ -331,10 +471,13 @@ int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, cons
                    const double* kff, const double* xref, const double* uref, const double* weighting,
                    const double* alphas_host, int nb_alphas, const int32_t* active, double* state, double* action,
                    double* cost, double* ret, int32_t* finite, hipStream_t st, int k_layout, int alpha_begin,
-                   int alpha_end, const int32_t* plist, const int32_t* pcount) {
+                   int alpha_end, const int32_t* plist, const int32_t* pcount, const RolloutBanks* banks) {
     if (alpha_begin < 0 || alpha_end > nb_alphas || alpha_begin >= alpha_end) return TRAJOPT_ERR_BAD_ARG;
+    if (banks && (layout != TRAJOPT_LAYOUT_PROBLEM_MINOR || !state || !action)) return TRAJOPT_ERR_BAD_ARG;
     RolloutLaunch L;
     L.a.alpha_begin = alpha_begin; L.a.plist = plist; L.a.pcount = pcount;
+    L.a.wbank = banks ? banks->wbank : nullptr; L.a.planes = banks ? banks->planes : 0;
+    L.tb = banks != nullptr;
     nb_alphas = alpha_end;  // the kernel runs alphas [alpha_begin, alpha_end)
     L.a.env = *env;
     L.a.x0 = x0; L.a.K = K; L.a.kff = kff; L.a.xref = xref; L.a.uref = uref; L.a.weighting = weighting;
@@ -363,7 +506,7 @@ int trajopt_ilqr_forward_pass_batched(const trajopt_env_t* env, int nb_steps, in
     if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
     return launch_rollout(env, nb_steps, nb_problems, layout, x0, K, kff, xref, uref, weighting, alphas_host, nb_alphas,
                           active, state, action, cost, ret, finite, as_stream(stream), layout, 0, nb_alphas, nullptr,
-                          nullptr);
+                          nullptr, nullptr);
 }
 
 int trajopt_env_step_batched(const trajopt_env_t* env, const double* x, const double* u, const double* u_last,
