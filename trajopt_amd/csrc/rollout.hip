@@ -55,6 +55,9 @@ __device__ __forceinline__ size_t gi(size_t e_total, size_t E_total, size_t p, s
 // neighbours in one bank (and whole 64-byte runs otherwise).  Rows are padded to 68 doubles: the transposed read
 // (lane = 8 problem + step -> address 68 step + problem) is then free of bank conflicts per half-wave.
 constexpr int kStageLd = 68;
+#ifndef ROLL_DIAG
+#define ROLL_DIAG 0   // timing experiments only (wrong results): 1 = no write-out of the staged blocks, 2 = no staging either
+#endif
 template <int ROWS>
 struct TbStage {
     double v[ROWS * kTB * kStageLd];
@@ -170,9 +173,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     // TB: element i of state slice s / element j of action slice t goes to the stage.  Both blocks b = t / 8 are
     // written out together after the step with t % 8 == 7 - BEFORE that step's new state, slice 8 b + 8, which is slot
     // 0 of the next block, is put - and whatever the last, partial blocks hold after the last step.
-    auto put_x = [&](int s, int i, double v) { s_stage.v[(i * kTB + (s & (kTB - 1))) * kStageLd + lane] = v; };
-    auto put_u = [&](int t, int j, double v) { s_stage.v[((n + j) * kTB + (t & (kTB - 1))) * kStageLd + lane] = v; };
+    auto put_x = [&](int s, int i, double v) { if (ROLL_DIAG >= 2) return; s_stage.v[(i * kTB + (s & (kTB - 1))) * kStageLd + lane] = v; };
+    auto put_u = [&](int t, int j, double v) { if (ROLL_DIAG >= 2) return; s_stage.v[((n + j) * kTB + (t & (kTB - 1))) * kStageLd + lane] = v; };
     auto flush_block = [&](int b) {
+        if (ROLL_DIAG >= 1) return;
         tb_flush(s_stage, s_stage.bx, a.state, 0, n, b, NP, lane);
         tb_flush(s_stage, s_stage.bu, a.action, n, m, b, NP, lane);
     };
@@ -194,9 +198,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         }
     if constexpr (FAST) {
         // The driver's variant.  Addresses are a wave-uniform slice pointer per array (advanced with scalar adds) plus
-        // a constant 32-bit per-lane offset per element, and the gains of step t+1 are loaded into the OTHER of two
-        // named register sets while step t integrates (unconditionally: the last slice is simply loaded twice) - the
-        // generic loop below costs ~65 address / copy instructions per step, a sixth of the step.
+        // a constant 32-bit per-lane offset per element, and the inputs of step t+2 are loaded into the register set of
+        // step t as soon as its control law has consumed them (two named sets; unconditionally: the last slice is simply
+        // loaded again) - the generic loop below costs ~65 address / copy instructions per step, a sixth of the step.
         static_assert(MINOR && SYS::kStatic, "FAST is instantiated for the struct-of-arrays layout and static dimensions only");
         struct In { double xr[N], ur[M], kf[M], K[M * N], w; };
         const unsigned np8 = (unsigned)(NP * 8), p8 = (unsigned)(p * 8);
@@ -240,7 +244,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         int t = 0;
         // put_next: the new state belongs to the block being filled (false only for the last step of a block, whose
         // new state the caller puts after the block has been written out)
-        auto step = [&](const In& s, auto put_next_c) {
+        // The step's inputs are consumed by its first few instructions (the control law and the cost); the register set
+        // is then refilled IN PLACE with the inputs of the step after next.  Two steps of distance matter because
+        // loads and stores retire through one in-order counter: a load issued behind the write-out of a block is only
+        // seen to have arrived once those 40 stores have been acknowledged.
+        auto step = [&](In& s, auto put_next_c) {
             constexpr bool put_next = decltype(put_next_c)::value;
             double u[M];  // u = clip(uref + alpha kff + K (x - xref))    objects.py:137-139, ilqr.py:97
 #pragma unroll
@@ -251,6 +259,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 u[j] = clip_g(fma(alpha, s.kf[j], s.ur[j]) + kx, e.umax[j]);
             }
             total += env_cost_plain<N, M>(e, x, u, s.w);  // ilqr.py:98 passes u_last = u_t
+            load(s);
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 if constexpr (TB) put_u(t, j, u[j]);
@@ -268,6 +277,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         };
         In sa, sb;
         load(sa);
+        load(sb);
         if constexpr (TB) {
             // Whole blocks: 8 steps, then both blocks go out - unconditional code in a loop with one entry state.  As
             // many stores are put behind the first load as a block's write-out puts behind every later one (block 0 as
@@ -279,10 +289,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
             for (int b = 0; b < nblk; ++b) {
 #pragma unroll
                 for (int k = 0; k < kTB / 2; ++k) {
-                    load(sb);
                     step(sa, std::true_type{});
                     ++t;
-                    load(sa);
                     if (k + 1 < kTB / 2) step(sb, std::true_type{});
                     else step(sb, std::false_type{});
                     ++t;
@@ -292,18 +300,16 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 for (int i = 0; i < N; ++i) put_x(t, i, x[i]);   // slice 8 b + 8 = slot 0 of the next block
             }
             while (t < T) {   // the last, partial block: fewer than 8 steps
-                load(sb);
                 step(sa, std::true_type{});
+                if (++t >= T) break;
+                step(sb, std::true_type{});
                 ++t;
-                sa = sb;
             }
             flush_tail();
         } else {
             while (t < T) {
-                load(sb);
                 step(sa, std::true_type{});
                 if (++t >= T) break;
-                load(sa);
                 step(sb, std::true_type{});
                 ++t;
             }
