@@ -50,17 +50,19 @@ __device__ __forceinline__ size_t gi(size_t e_total, size_t E_total, size_t p, s
 // Staging of a wave's candidate stores for the time-blocked planes (TB; common.h).  A lane produces one double per
 // element and step, but a plane wants the 8 steps of a block next to each other: written as they come, every store
 // instruction would touch 32 cache lines with 16 bytes each (measured: the rollout took twice as long).  So the wave
-// collects a block - 8 steps x 64 lanes per element - in LDS and writes it out transposed: store k of a row covers
-// the lane-problems 8 k .. 8 k + 7 with their 8 steps each, 512 contiguous bytes when the wave's problems are
-// neighbours in one bank (and whole 64-byte runs otherwise).  Rows are padded to 68 doubles: the transposed read
-// (lane = 8 problem + step -> address 68 step + problem) is then free of bank conflicts per half-wave.
-constexpr int kStageLd = 68;
+// collects a block - 8 steps x 64 lanes per element - in LDS, the 8 steps of a lane next to each other, and writes
+// it out 16 bytes a lane: store k of a row covers the lane-problems 16 k .. 16 k + 15 with their 8 steps each, 1 KB
+// contiguous when the wave's problems are neighbours in one bank (and whole 64-byte runs otherwise) - half as many
+// LDS reads and store instructions as 8 bytes a lane.  A lane's 8 steps are padded to 10 doubles (16-byte aligned
+// reads; the puts of a step are then a 2-way bank conflict, the cheapest padding that keeps the alignment).
+constexpr int kStagePad = 10;
 #ifndef ROLL_DIAG
 #define ROLL_DIAG 0   // timing experiments only (wrong results): 1 = no write-out of the staged blocks, 2 = no staging either
 #endif
+typedef double stage_v2 __attribute__((ext_vector_type(2)));
 template <int ROWS>
-struct TbStage {
-    double v[ROWS * kTB * kStageLd];
+struct alignas(16) TbStage {
+    double v[ROWS * 64 * kStagePad];
     unsigned long long bx[64], bu[64];   // per lane-problem: element offset of (block 0, row 0) in state / action
 };
 // rows [row0, row0 + rows) of the stage = block `blk` of `base` (a plane set with `rows` rows per block)
@@ -72,14 +74,16 @@ __device__ __forceinline__ void tb_flush(const TbStage<ROWS>& sg, const unsigned
                                          int rows, int blk, size_t NP, unsigned lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const unsigned step = lane & (kTB - 1), pj = lane >> 3;
+    const unsigned sp = lane & 3u, pj = lane >> 2;   // the lane's pair of steps, its problem among the store's 16
     const size_t rstride = NP * kTB;
-    double* dst0 = base + ((size_t)blk * rows) * rstride + step;
+    double* dst0 = base + ((size_t)blk * rows) * rstride + 2 * sp;
 #pragma unroll
-    for (int k = 0; k < 64 / kTB; ++k) {
-        const unsigned prob = (unsigned)k * (64 / kTB) + pj;
+    for (int k = 0; k < 4; ++k) {
+        const unsigned prob = (unsigned)k * 16 + pj;
         double* d = dst0 + off[prob];
-        for (int r = 0; r < rows; ++r) d[(size_t)r * rstride] = sg.v[((row0 + r) * kTB + step) * kStageLd + prob];
+        for (int r = 0; r < rows; ++r)
+            *reinterpret_cast<stage_v2*>(d + (size_t)r * rstride) =
+                *reinterpret_cast<const stage_v2*>(&sg.v[((row0 + r) * 64 + prob) * kStagePad + 2 * sp]);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -173,8 +177,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     // TB: element i of state slice s / element j of action slice t goes to the stage.  Both blocks b = t / 8 are
     // written out together after the step with t % 8 == 7 - BEFORE that step's new state, slice 8 b + 8, which is slot
     // 0 of the next block, is put - and whatever the last, partial blocks hold after the last step.
-    auto put_x = [&](int s, int i, double v) { if (ROLL_DIAG >= 2) return; s_stage.v[(i * kTB + (s & (kTB - 1))) * kStageLd + lane] = v; };
-    auto put_u = [&](int t, int j, double v) { if (ROLL_DIAG >= 2) return; s_stage.v[((n + j) * kTB + (t & (kTB - 1))) * kStageLd + lane] = v; };
+    auto put_x = [&](int s, int i, double v) { if (ROLL_DIAG >= 2) return; s_stage.v[(i * 64 + lane) * kStagePad + (s & (kTB - 1))] = v; };
+    auto put_u = [&](int t, int j, double v) { if (ROLL_DIAG >= 2) return; s_stage.v[((n + j) * 64 + lane) * kStagePad + (t & (kTB - 1))] = v; };
     auto flush_block = [&](int b) {
         if (ROLL_DIAG >= 1) return;
         tb_flush(s_stage, s_stage.bx, a.state, 0, n, b, NP, lane);
