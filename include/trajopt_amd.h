@@ -137,14 +137,16 @@ typedef struct trajopt_backward_io {
      * run every family against the oracle) and returns TRAJOPT_ERR_UNSUPPORTED where it has no kernel for the shape. */
     int32_t kernel;
     int32_t pad_;
-    /* Optional double-buffered gains (ABI v5; the batched driver's, NULL for everybody else).  With out_bank
-     * non-NULL, K and kff hold TWO banks each and problem p's gains are written to bank out_bank[p] (0 or 1):
-     *   PROBLEM_MINOR  K(p, e, t, b) = K[((2 t + b) m n + e) nb_problems + p]      (banks interleaved per time step)
-     *   PROBLEM_MAJOR  K(p, e, t, b) = K[(b nb_problems + p) m n T + m n t + e]    (bank slowest)
-     * and the same for kff with m in place of m n.  The other bank of a problem is left untouched: it holds the gains
-     * of its last ACCEPTED iterate while a new candidate is computed (ilqr.py:214 without a copy). */
+    /* Optional multi-buffered gains (ABI v5; the batched driver's, NULL for everybody else).  With out_bank non-NULL,
+     * K and kff hold TRAJOPT_GAIN_BANKS banks each and problem p's gains are written to bank out_bank[p]:
+     *   PROBLEM_MINOR  K(p, e, t, b) = K[((TRAJOPT_GAIN_BANKS t + b) m n + e) nb_problems + p]   (banks interleaved per time step)
+     *   PROBLEM_MAJOR  K(p, e, t, b) = K[(b nb_problems + p) m n T + m n t + e]                   (bank slowest)
+     * and the same for kff with m in place of m n.  The other banks of a problem are left untouched: one of them may
+     * hold the gains of its last ACCEPTED iterate while a new candidate is computed (ilqr.py:214 without a copy). */
     const int32_t* out_bank;
 } trajopt_backward_io_t;
+
+#define TRAJOPT_GAIN_BANKS 3
 
 #define TRAJOPT_KERNEL_AUTO 0
 #define TRAJOPT_KERNEL_WORKGROUP 1   /* workgroup = problem, any dx <= 64, du <= 16 (bwd_wg.hip)                    */
@@ -394,24 +396,30 @@ typedef struct trajopt_ilqr_workspace {
     int32_t* cand_finite;
     int32_t* pending_list;   /* [nb_problems], staged line search only (may be NULL otherwise) */
     int32_t* pending_count;  /* [1] */
-    /* ABI v5: no copy on accept.  cand_state / cand_action hold 2 * nb_alphas planes (two banks of nb_alphas) and
-     * cand_K / cand_kff two banks (layout: trajopt_backward_io_t::out_bank).  An iteration writes its candidates and
-     * gains into bank wbank[p] and reads the reference trajectory of problem p from plane ref_plane[p]; accepting
-     * alpha k is  ref_plane[p] = wbank[p] * nb_alphas + k, wbank[p] ^= 1  (ilqr.py:210-217).  Neighbouring problems
-     * read different planes, so a plane is TIME-BLOCKED - 8 consecutive steps of one element of one problem are one
-     * 64-byte run, which its reader uses in full:
+    /* ABI v5: no copy on accept.  cand_state / cand_action hold 2 * nb_alphas + 1 planes - two banks of nb_alphas and
+     * one plane nobody reads (lanes of stopped problems write there).  Iteration i of a trajopt_ilqr_iterate call
+     * writes its candidates into bank i % 2, for every problem, and accepting alpha k (ilqr.py:210-217) is
+     *     ref_plane[p] = (i % 2) * nb_alphas + k,   gains_bank[p] = out_bank[p]:
+     * the reference trajectory of problem p is then read from that plane.  A reference still in the bank about to be
+     * written (its problem has rejected every alpha since) already has a copy in xref / uref - the quadratisation
+     * writes what it reads through, every iteration - so ref_plane[p] just becomes -1 = "in xref / uref".
+     * cand_K / cand_kff hold TRAJOPT_GAIN_BANKS banks (layout: trajopt_backward_io_t::out_bank): problem p writes its
+     * gains to bank out_bank[p] = i % 2, unless that bank holds its accepted controller (gains_bank[p]; it has rejected
+     * every alpha since) - then to bank 2.  Nothing is ever copied, and all but the rejecting problems write the same
+     * bank, whole cache lines at a time.  gains_bank[p] = -1 means "in K / kff".
+     * At the end of every call xref / uref / K / kff are brought up to date and ref_plane / gains_bank are -1 again -
+     * the state a fresh workspace must have.
+     * Neighbouring problems read different planes, so a plane is TIME-BLOCKED - 8 consecutive steps of one element
+     * of one problem are one 64-byte run, which its reader uses in full:
      *     plane(p, e, t) = plane[(((t / 8) rows + e) nb_problems + p) 8 + t % 8],
-     *     plane size = ceil(slices / 8) * 8 * rows * nb_problems   (state: rows n, slices T + 1; action: m, T).
-     * ref_plane[p] < 0 (a fresh workspace) means "the reference is in xref / uref": the driver then plants it into
-     * plane 0.  xref / K / kff are brought up to date once, at the end of every trajopt_ilqr_iterate call (uref in
-     * every iteration); between calls they may be read, not written - trajopt_ilqr_init_rollout re-arms both arrays. */
+     *     plane size = ceil(slices / 8) * 8 * rows * nb_problems   (state: rows n, slices T + 1; action: m, T). */
     int32_t* ref_plane;      /* [nb_problems] */
-    int32_t* wbank;          /* [nb_problems] */
+    int32_t* gains_bank;     /* [nb_problems] */
+    int32_t* out_bank;       /* [nb_problems] */
 } trajopt_ilqr_workspace_t;
 
 /* ilqr.py:139-149: initial rollout of ws->K / ws->kff over the alphas; first one with all(state < 1e8)
- * becomes xref/uref/last_return and trace[0].  Also copies ws->K / ws->kff into bank 0 of cand_K / cand_kff and
- * initialises ref_plane / wbank. */
+ * becomes xref/uref/last_return and trace[0]; ref_plane / gains_bank are reset to -1. */
 int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
                               const trajopt_ilqr_workspace_t* ws, void* stream);
 /* `nb_iter` iterations of ilqr.py:151-231 for every problem whose status is 0, without any host

@@ -46,7 +46,7 @@ int main(void) {
   printf("io %zu %zu %zu %zu\n", sizeof(trajopt_backward_io_t), offsetof(trajopt_backward_io_t, dV), offsetof(trajopt_backward_io_t, active), offsetof(trajopt_backward_io_t, out_bank));
   printf("opt %zu %zu %zu %zu\n", sizeof(trajopt_ilqr_options_t), offsetof(trajopt_ilqr_options_t, alphas), offsetof(trajopt_ilqr_options_t, keep_value), offsetof(trajopt_ilqr_options_t, no_fusion));
   printf("plan %zu\n", sizeof(trajopt_ilqr_plan_t));
-  printf("ws %zu %zu %zu %zu\n", sizeof(trajopt_ilqr_workspace_t), offsetof(trajopt_ilqr_workspace_t, trace_cap), offsetof(trajopt_ilqr_workspace_t, A), offsetof(trajopt_ilqr_workspace_t, wbank));
+  printf("ws %zu %zu %zu %zu\n", sizeof(trajopt_ilqr_workspace_t), offsetof(trajopt_ilqr_workspace_t, trace_cap), offsetof(trajopt_ilqr_workspace_t, A), offsetof(trajopt_ilqr_workspace_t, out_bank));
   return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
@@ -59,7 +59,7 @@ int main(void) {
     assert got[1] == "io %d %d %d %d" % (C.sizeof(IO), IO.dV.offset, IO.active.offset, IO.out_bank.offset)
     assert got[2] == "opt %d %d %d %d" % (C.sizeof(OP), OP.alphas.offset, OP.keep_value.offset, OP.no_fusion.offset)
     assert got[3] == "plan %d" % C.sizeof(_lib.ILQRPlan)
-    assert got[4] == "ws %d %d %d %d" % (C.sizeof(WS), WS.trace_cap.offset, WS.A.offset, WS.wbank.offset)
+    assert got[4] == "ws %d %d %d %d" % (C.sizeof(WS), WS.trace_cap.offset, WS.A.offset, WS.out_bank.offset)
     assert C.sizeof(O.EnvStruct) == C.sizeof(E)   # the oracle's mirror of the same POD
 
 

@@ -165,7 +165,7 @@ def test_ilqr_iteration_full_size_c4_eight_alphas(oracle):
     from oracle import oracle as O
     s = _tiled_iteration(oracle, "quadrotor", dict(dt=0.02, uw=1e-3), 4096, 32, 500, 3, O.DEFAULT_ALPHAS[:8], 4,
                          kff_bias=0.5 * 9.81 / 4)
-    assert s.alphas.size == 8 and s._cand_state.shape[0] == 16
+    assert s.alphas.size == 8 and s._cand_state.shape[0] == 17
 
 
 def test_sharded_ilqr_world_size_one_is_the_batched_solver(oracle):

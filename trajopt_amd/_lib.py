@@ -95,7 +95,7 @@ class ILQRWorkspace(C.Structure):
                  ("A", "B", "Cxx", "cx", "Cuu", "cu", "Cxu", "cand_K", "cand_kff", "cand_V", "cand_v", "cand_Qxx",
                   "cand_Qux", "cand_Quu", "cand_qx", "cand_qu", "dV", "g_norm", "diverge", "active", "sel",
                   "cand_state", "cand_action", "cand_ret", "cand_finite", "pending_list", "pending_count",
-                  "ref_plane", "wbank")])
+                  "ref_plane", "gains_bank", "out_bank")])
 
 
 # every symbol include/trajopt_amd.h declares

@@ -37,7 +37,7 @@ __device__ __forceinline__ size_t at(size_t eps, size_t slices, int t, size_t e,
     return MINOR ? (eps * (size_t)t + e) * NP + p : p * eps * slices + eps * (size_t)t + e;
 }
 
-// the same for the gains K / kff, which may hold two banks (trajopt_backward_io_t::out_bank; kmul = 2 with banks)
+// the same for the gains K / kff, which may hold TRAJOPT_GAIN_BANKS banks (trajopt_backward_io_t::out_bank; kmul = their number)
 template <bool MINOR>
 __device__ __forceinline__ size_t at_gain(size_t eps, size_t slices, int t, size_t e, size_t p, size_t NP, int kmul,
                                           int bank) {
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
     const bool live = c < n;
     const bool want_gn = io.uref != nullptr && io.g_norm != nullptr;
-    const int kmul = io.out_bank ? 2 : 1, bank = gains_bank(io.out_bank, p);
+    const int kmul = io.out_bank ? TRAJOPT_GAIN_BANKS : 1, bank = gains_bank(io.out_bank, p);
     // F in B layout: Fb[s] = F[4s + g][c] is one slot walked with a fixed row offset of 4 rows per k-step
     const ptrdiff_t row4 = MINOR ? (ptrdiff_t)(4 * NP) : 4;
 

@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256, 2) void bwd_mfma4_kernel(M4Args a) {
         return M4Off{o0.rc + tn * s_nn, o0.r + tn * s_n, o0.c + tn * s_n, o0.z + tn * s_1};
     };
     auto back = [&](M4Off& o) { o.rc -= s_nn; o.r -= s_n; o.c -= s_n; o.z -= s_1; };
-    // gains: bank io.out_bank[p] of the two interleaved per time step (trajopt_backward_io_t::out_bank); du = 1
-    const unsigned kmul = a.io.out_bank ? 2u : 1u, bank = (unsigned)gains_bank(a.io.out_bank, p);
+    // gains: bank io.out_bank[p] of those interleaved per time step (trajopt_backward_io_t::out_bank); du = 1
+    const unsigned kmul = a.io.out_bank ? (unsigned)TRAJOPT_GAIN_BANKS : 1u, bank = (unsigned)gains_bank(a.io.out_bank, p);
     const unsigned gK0 = (bank * N + cc) * np8 + p8, gk0 = bank * np8 + p8, gs_n = kmul * s_n, gs_1 = kmul * s_1;
     // Stores need no lane predicate for N = 4: a value replicated over r (or c, or the whole block) is written by
     // all its holders to the one address - same value, same address, merged by the memory pipeline.
@@ -373,6 +373,7 @@ int launch_backward_mfma4(const trajopt_backward_io_t& io, int reg, int n, int m
     *handled = false;
     if (m != 1 || n < 2 || n > 4) return TRAJOPT_OK;
     if ((double)(T + 2) * n * n * (double)NP * 8.0 >= 4294967296.0) return TRAJOPT_OK;
+    if (io.out_bank && (double)TRAJOPT_GAIN_BANKS * (T + 1) * n * (double)NP * 8.0 >= 4294967296.0) return TRAJOPT_OK;
     M4Args a;
     a.io = io; a.sched = sched; a.NP = (size_t)NP; a.T = T; a.reg = reg; a.retry = retry;
     *handled = true;

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
     const size_t NP = a.NP;
     const int T = a.T;
     const Lane off{lane * 8u, NP};  // host guarantees N*N*NP*8 + 512 < 2^32
-    const int kmul = a.io.out_bank ? 2 : 1;
+    const int kmul = a.io.out_bank ? TRAJOPT_GAIN_BANKS : 1;
     const unsigned bank = (unsigned)gains_bank(a.io.out_bank, p);
     const Lane offK{lane * 8u + bank * (unsigned)(N * M * NP * 8), NP}, offkff{lane * 8u + bank * (unsigned)(M * NP * 8), NP};
     double lam = a.io.lmbda[p];
@@ -439,6 +439,8 @@ int launch_backward_tpp(const trajopt_backward_io_t& io, int reg, int n, int m, 
     a.reg = reg;
     a.retry = retry;
     a.lpw = pick_lpw(a.NP);
+    *handled = false;
+    if (io.out_bank && (double)TRAJOPT_GAIN_BANKS * n * m * (double)NP * 8.0 + 512.0 >= 4294967296.0) return TRAJOPT_OK;   // 32-bit lane offsets
     *handled = true;
     if (n == 2 && m == 1) return launch_nm<2, 1>(a, st);
     if (n == 3 && m == 1) return launch_nm<3, 1>(a, st);

@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void bwd_wg_kernel(WgArgs a) {
     const size_t p = blockIdx.x;
     if (VARIANT == 0 && a.io.active && a.io.active[p] == 0) return;
     const G<MINOR> g{a.NP, p};
-    // gains K / kff: bank io.out_bank[p] of two when the driver double-buffers them (trajopt_backward_io_t::out_bank)
-    const int kmul = (VARIANT == 0 && a.io.out_bank) ? 2 : 1, bank = VARIANT == 0 ? gains_bank(a.io.out_bank, p) : 0;
+    // gains K / kff: bank io.out_bank[p] when the driver keeps several (trajopt_backward_io_t::out_bank)
+    const int kmul = (VARIANT == 0 && a.io.out_bank) ? TRAJOPT_GAIN_BANKS : 1, bank = VARIANT == 0 ? gains_bank(a.io.out_bank, p) : 0;
     auto gK = [&](size_t eps, size_t slices, int t, size_t e) -> size_t {
         return MINOR ? (eps * (size_t)(kmul * t + bank) + e) * a.NP + p
                      : ((size_t)bank * a.NP + p) * eps * slices + eps * (size_t)t + e;

@@ -55,26 +55,27 @@ __host__ __device__ inline size_t tb_index(int rows, int t, int e, size_t p, siz
 }
 
 // Where the driver's quadratisation finds the reference trajectory: states / actions of problem p in time-blocked
-// plane ref_plane[p] (>= 0 for every problem once trajopt_ilqr_init_rollout / the driver's plant step has run) of
-// cand_state / cand_action.  xref_out / uref_out: what it read is written through to these dense PROBLEM_MINOR arrays
-// (the workspace's xref / uref), from which the backward pass (gradient norm, ilqr.py:176) and the rollout - whose
-// lanes of one problem sit in eleven different waves - take the reference with wave-uniform, coalesced addressing.
+// plane ref_plane[p] of cand_state / cand_action, or - ref_plane[p] < 0 - in the dense xref / uref the kernel is given.
+// What it reads from a plane is written through to xref_out / uref_out (the workspace's dense PROBLEM_MINOR xref /
+// uref), from which the backward pass (gradient norm, ilqr.py:176) and the rollout - whose lanes of one problem sit in
+// eleven different waves - take the reference with wave-uniform, coalesced addressing, and where it survives when the
+// plane is written again.
 struct RefView {
-    const int32_t* ref_plane;  // NULL: the dense xref / uref arrays the kernel is given, for every problem
+    const int32_t* ref_plane;  // NULL: the dense xref / uref for every problem
     const double *cand_state, *cand_action;
     double *xref_out, *uref_out;
 };
 
-// The rollout's side of the same scheme: its candidates go, time-blocked, into bank wbank[p] (of `planes` planes
-// each; bank 0 without wbank) of cand_state / cand_action, and it reads the gains from that bank of the
-// double-buffered K / kff.  Its reference comes from the dense xref / uref the quadratisation writes through.
-struct RolloutBanks {
-    const int32_t* wbank;
-    int planes;
+// The rollout's side: its candidates go, time-blocked, into planes [first_plane, first_plane + nb_alphas) of
+// cand_state / cand_action - the bank of this iteration - and the lanes of stopped problems (which run along, see
+// rollout.hip) into junk_plane; the gains of problem p come from bank out_bank[p] (trajopt_backward_io_t::out_bank).
+struct RolloutPlanes {
+    int first_plane, junk_plane;
+    const int32_t* out_bank;   // bank of the multi-buffered gains each problem reads (NULL: plain K / kff)
 };
 
-// Bank of the double-buffered gains problem p writes (trajopt_backward_io_t::out_bank), 0 without banks.
-__device__ __forceinline__ int gains_bank(const int32_t* out_bank, size_t p) { return out_bank ? (out_bank[p] & 1) : 0; }
+// Bank of the multi-buffered gains problem p writes (trajopt_backward_io_t::out_bank), 0 without banks.
+__device__ __forceinline__ int gains_bank(const int32_t* out_bank, size_t p) { return out_bank ? out_bank[p] : 0; }
 
 // Kernel launchers implemented per translation unit (all return TRAJOPT_* codes).
 int launch_backward_tpp(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int retry,

@@ -5,9 +5,10 @@
 //   quadratise -> backward pass (lambda retries inside the kernel, ilqr.py:162-173)   [one fused launch for small
 //        dx <= 4 batches] -> gradient-norm stop (ilqr.py:176-180) -> rollout of every alpha at once (ilqr.py:187-191)
 //        -> first-accept selection + lambda update + stopping rules (ilqr.py:193-231).
-// Accepting a candidate (ilqr.py:210-217) copies nothing: candidates and gains are double-buffered per problem and an
-// accept only moves ref_plane[p] / wbank[p] (include/trajopt_amd.h, ABI v5); xref / K / kff are brought up to date once
-// per trajopt_ilqr_iterate call.  Problems that have stopped keep their slot and are masked out through `active`
+// Accepting a candidate (ilqr.py:210-217) copies nothing: iteration i writes candidates and gains into bank i % 2 and
+// an accept only sets ref_plane[p] / gains_bank[p] (include/trajopt_amd.h, ABI v5); a problem that has rejected every
+// alpha keeps its reference in xref / uref (written through by the quadratisation) and writes its next gains into a
+// third bank; xref / K / kff are brought up to date once per trajopt_ilqr_iterate call.  Problems that have stopped keep their slot and are masked out through `active`
 // (SURVEY 9.5).  Everything is PROBLEM_MINOR except the gains group (ws->gains_layout, see include/trajopt_amd.h).
 #include "sys.h"
 
@@ -17,7 +18,7 @@ int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, cons
                    const double* kff, const double* xref, const double* uref, const double* weighting,
                    const double* alphas_host, int nb_alphas, const int32_t* active, double* state, double* action,
                    double* cost, double* ret, int32_t* finite, hipStream_t st, int k_layout, int alpha_begin,
-                   int alpha_end, const int32_t* plist, const int32_t* pcount, const RolloutBanks* banks);
+                   int alpha_end, const int32_t* plist, const int32_t* pcount, const RolloutPlanes* planes);
 int launch_quadratize(const trajopt_env_t* env, int T, int64_t NP, int layout, int convention, const double* xref,
                       const double* uref, const double* weighting, const int32_t* active, double* A, double* B,
                       double* c, double* Cxx, double* cx, double* Cuu, double* cu, double* Cxu, hipStream_t st,
@@ -62,10 +63,10 @@ __global__ void init_select_kernel(DrvArgs a) {
     for (int k = 0; k < a.opt.nb_alphas; ++k)
         if (a.ws.cand_finite[(size_t)k * NP + p] && isfinite(a.ws.cand_ret[(size_t)k * NP + p])) { sel = k; break; }
     a.ws.sel[p] = sel;
-    // the initial rollout wrote its candidates into bank 0: the reference is plane `sel` there (none finite: whatever
-    // xref / uref hold), and the first iteration writes bank 1
+    // the initial rollout wrote its candidates into bank 0: plane `sel` there is published to xref / uref right away
+    // (none finite: they keep what they hold), trajopt_ilqr_init_rollout then resets ref_plane to -1
     a.ws.ref_plane[p] = sel;
-    a.ws.wbank[p] = 1;
+    a.ws.gains_bank[p] = -1;
     // no finite alpha: last_return keeps its previous value (-inf on a fresh solver, ilqr.py:87)
     const double r = sel >= 0 ? a.ws.cand_ret[(size_t)sel * NP + p] : a.ws.last_return[p];
     a.ws.last_return[p] = r;
@@ -76,22 +77,30 @@ __global__ void init_select_kernel(DrvArgs a) {
 }
 
 // Start of an iteration (ilqr.py:151): a problem takes part while its status is 0.
-__device__ __forceinline__ void prep_problem(const DrvArgs& a, size_t p) {
+// wb: the bank the coming iteration writes.  A problem's gains go there too - unless that bank holds its accepted
+// controller (it has rejected every alpha since): then to the spare bank, so that nothing accepted is ever overwritten.
+__device__ __forceinline__ void prep_problem(const DrvArgs& a, size_t p, int wb) {
     const int act = a.ws.status[p] == 0 ? 1 : 0;
     a.ws.active[p] = act;
     if (act) a.ws.iters[p] += 1;
+    a.ws.out_bank[p] = a.ws.gains_bank[p] == wb ? TRAJOPT_GAIN_BANKS - 1 : wb;
 }
-__global__ void prep_kernel(DrvArgs a) {
+__global__ void prep_kernel(DrvArgs a, int wb) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (size_t)a.ws.nb_problems) return;
-    prep_problem(a, p);
+    prep_problem(a, p, wb);
 }
 
 // ilqr.py:175-180 plus the "backward pass gave up" path (:168 -> :224-231).
-__global__ void post_backward_kernel(DrvArgs a) {
+// Also, for bank wb, which this iteration's rollout is about to write: a reference that still lives in one of its
+// planes (the problem rejected every alpha since) is from now on the copy the quadratisation has just written through to
+// xref / uref.
+__global__ void post_backward_kernel(DrvArgs a, int wb) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (size_t)a.ws.nb_problems) return;
     if (!a.ws.active[p]) return;
+    const int ref = a.ws.ref_plane[p];
+    if (ref >= 0 && ref / a.opt.nb_alphas == wb) a.ws.ref_plane[p] = -1;
     double lam = a.ws.lmbda[p], dlam = a.ws.dlmbda[p];
     const double g = a.ws.g_norm[p];
     if (g < a.opt.tolgrad && lam < 1e-5) {
@@ -135,15 +144,16 @@ __global__ void pending_kernel(DrvArgs a) {
 // prep_next: another iteration follows in this call - its prep (same thread-per-problem mapping, nothing reads `active`
 // in between) is done here instead of in a launch of its own.
 // staged: pending_kernel has already decided alphas[0] for this problem (sel[p]).
-__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP, int staged);
-__global__ void select_kernel(DrvArgs a, int prep_next, int staged) {
+// wb: the bank this iteration wrote.
+__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP, int staged, int wb);
+__global__ void select_kernel(DrvArgs a, int prep_next, int staged, int wb) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t NP = (size_t)a.ws.nb_problems;
     if (p >= NP) return;
-    select_problem(a, p, NP, staged);
-    if (prep_next) prep_problem(a, p);
+    select_problem(a, p, NP, staged, wb);
+    if (prep_next) prep_problem(a, p, wb ^ 1);
 }
-__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP, int staged) {
+__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP, int staged, int wb) {
     const bool first_accepted = staged && a.ws.sel[p] == 0;
     a.ws.sel[p] = -1;
     if (!a.ws.active[p]) return;
@@ -190,11 +200,10 @@ __device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_
         }
         if (dret_sel < a.opt.tolfun) a.ws.status[p] = 2;  // ilqr.py:222
         a.ws.sel[p] = sel;
-        // ilqr.py:210-217 without a copy: the candidate's plane IS the reference from now on, its gains' bank holds
-        // the accepted controller, and the next iteration writes the other bank
-        const int wb = a.ws.wbank[p] & 1;
+        // ilqr.py:210-217 without a copy: the candidate's plane IS the reference from now on and the bank the backward
+        // pass wrote this problem's gains to holds the accepted controller
         a.ws.ref_plane[p] = wb * a.opt.nb_alphas + sel;
-        a.ws.wbank[p] = wb ^ 1;
+        a.ws.gains_bank[p] = a.ws.out_bank[p];
     } else {
         grow_lambda(lam, dlam, a.opt.sched);
         if (lam > a.opt.sched.max_lmbda) a.ws.status[p] = 3;  // ilqr.py:228
@@ -209,14 +218,16 @@ template <bool GMINOR>
 __device__ __forceinline__ size_t gidx(size_t eps, size_t slices, int t, size_t e, size_t p, size_t NP) {
     return GMINOR ? (eps * (size_t)t + e) * NP + p : p * eps * slices + eps * (size_t)t + e;
 }
-// The same inside bank b of the double-buffered cand_K / cand_kff (trajopt_backward_io_t::out_bank).
+// The same inside bank b of the multi-buffered cand_K / cand_kff (trajopt_backward_io_t::out_bank).
 template <bool GMINOR>
 __device__ __forceinline__ size_t gidx_bank(size_t eps, size_t slices, int t, size_t e, size_t p, size_t NP, int b) {
-    return GMINOR ? (eps * (size_t)(2 * t + b) + e) * NP + p : ((size_t)b * NP + p) * eps * slices + eps * (size_t)t + e;
+    return GMINOR ? (eps * (size_t)(TRAJOPT_GAIN_BANKS * t + b) + e) * NP + p
+                  : ((size_t)b * NP + p) * eps * slices + eps * (size_t)t + e;
 }
 
 // Bring xref / uref (and, with_ctl, K / kff) up to date with the accepted iterate (ilqr.py:210-217 / :142-143): copy
-// plane ref_plane[p] and the gains of its bank.  Thread per (problem, step); once per driver call, not per iteration.
+// plane ref_plane[p] and the gains of bank gains_bank[p].
+// Thread per (problem, step); once per driver call, not per iteration.
 template <bool GMINOR>
 __global__ void publish_kernel(DrvArgs a, int with_ctl) {
     const size_t NP = (size_t)a.ws.nb_problems;
@@ -226,43 +237,26 @@ __global__ void publish_kernel(DrvArgs a, int with_ctl) {
     const int t = (int)blockIdx.y;
     if (p >= NP) return;
     const int ref = a.ws.ref_plane[p];
-    if (ref < 0) return;
-    const double* st = a.ws.cand_state + (size_t)ref * tb_plane(n, T + 1, NP);
-    for (int i = 0; i < n; ++i) a.ws.xref[((size_t)n * t + i) * NP + p] = st[tb_index(n, t, i, p, NP)];
-    if (t >= T) return;
-    const double* ac = a.ws.cand_action + (size_t)ref * tb_plane(m, T, NP);
-    for (int j = 0; j < m; ++j) a.ws.uref[((size_t)m * t + j) * NP + p] = ac[tb_index(m, t, j, p, NP)];
-    if (!with_ctl) return;
-    const int b = ref / a.opt.nb_alphas;
+    if (ref >= 0) {
+        const double* st = a.ws.cand_state + (size_t)ref * tb_plane(n, T + 1, NP);
+        for (int i = 0; i < n; ++i) a.ws.xref[((size_t)n * t + i) * NP + p] = st[tb_index(n, t, i, p, NP)];
+        if (t < T) {
+            const double* ac = a.ws.cand_action + (size_t)ref * tb_plane(m, T, NP);
+            for (int j = 0; j < m; ++j) a.ws.uref[((size_t)m * t + j) * NP + p] = ac[tb_index(m, t, j, p, NP)];
+        }
+    }
+    const int b = with_ctl ? a.ws.gains_bank[p] : -1;
+    if (b < 0 || t >= T) return;
     const size_t nm = (size_t)n * m;
     for (size_t k = 0; k < nm; ++k) a.ws.K[gidx<GMINOR>(nm, T, t, k, p, NP)] = a.ws.cand_K[gidx_bank<GMINOR>(nm, T, t, k, p, NP, b)];
     for (size_t k = 0; k < (size_t)m; ++k) a.ws.kff[gidx<GMINOR>(m, T, t, k, p, NP)] = a.ws.cand_kff[gidx_bank<GMINOR>(m, T, t, k, p, NP, b)];
 }
-
-// The reverse, for a problem whose reference is not in a plane yet (ref_plane[p] < 0: no finite initial rollout,
-// ilqr.py:139-147, or a workspace handed to trajopt_ilqr_iterate without trajopt_ilqr_init_rollout): xref / uref / K /
-// kff are planted into plane 0 and gains bank 0, and plant_finish_kernel then points the problem there.
-template <bool GMINOR>
-__global__ void plant_kernel(DrvArgs a) {
-    const size_t NP = (size_t)a.ws.nb_problems;
-    const int T = a.ws.nb_steps, n = a.n, m = a.m;
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int t = (int)blockIdx.y;
-    if (p >= NP) return;
-    if (a.ws.ref_plane[p] >= 0) return;
-    for (int i = 0; i < n; ++i) a.ws.cand_state[tb_index(n, t, i, p, NP)] = a.ws.xref[((size_t)n * t + i) * NP + p];
-    if (t >= T) return;
-    for (int j = 0; j < m; ++j) a.ws.cand_action[tb_index(m, t, j, p, NP)] = a.ws.uref[((size_t)m * t + j) * NP + p];
-    const size_t nm = (size_t)n * m;
-    for (size_t k = 0; k < nm; ++k) a.ws.cand_K[gidx_bank<GMINOR>(nm, T, t, k, p, NP, 0)] = a.ws.K[gidx<GMINOR>(nm, T, t, k, p, NP)];
-    for (size_t k = 0; k < (size_t)m; ++k) a.ws.cand_kff[gidx_bank<GMINOR>(m, T, t, k, p, NP, 0)] = a.ws.kff[gidx<GMINOR>(m, T, t, k, p, NP)];
-}
-__global__ void plant_finish_kernel(DrvArgs a) {
+// ... after which every reference and every accepted controller is in the dense arrays
+__global__ void published_kernel(DrvArgs a) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (size_t)a.ws.nb_problems) return;
-    if (a.ws.ref_plane[p] >= 0) return;
-    a.ws.ref_plane[p] = 0;
-    a.ws.wbank[p] = 1;
+    a.ws.ref_plane[p] = -1;
+    a.ws.gains_bank[p] = -1;
 }
 
 // keep_value only: promote the value / Q-function arrays of the problems that accepted in this iteration
@@ -301,7 +295,7 @@ __global__ __launch_bounds__(64) void gnorm_major_kernel(DrvArgs a) {
         double mx = -INFINITY;
         bool nan_seen = false;
         for (int t = lane; t < T; t += 64) {
-            const double q = fabs(a.ws.cand_kff[((size_t)(a.ws.wbank[p] & 1) * NP + p) * (size_t)m * T + (size_t)m * t + j]) /
+            const double q = fabs(a.ws.cand_kff[((size_t)a.ws.out_bank[p] * NP + p) * (size_t)m * T + (size_t)m * t + j]) /
                              (fabs(a.ws.uref[((size_t)m * t + j) * NP + p]) + 1.0);
             nan_seen = nan_seen || (q != q);
             mx = fmax(mx, q);
@@ -342,7 +336,7 @@ static int check_ws(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
                           ws->dlmbda, ws->alpha, ws->status, ws->iters, ws->trace_len, ws->trace, ws->A, ws->B,
                           ws->Cxx, ws->cx, ws->Cuu, ws->cu, ws->Cxu, ws->cand_K, ws->cand_kff, ws->dV, ws->g_norm,
                           ws->diverge, ws->active, ws->sel, ws->cand_state, ws->cand_action, ws->cand_ret,
-                          ws->cand_finite, ws->ref_plane, ws->wbank};
+                          ws->cand_finite, ws->ref_plane, ws->gains_bank, ws->out_bank};
     for (const void* q : need)
         if (!q) return TRAJOPT_ERR_BAD_ARG;
     if (opt->keep_value) {
@@ -370,32 +364,18 @@ int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_optio
     hipStream_t st = as_stream(stream);
     const int64_t NP = ws->nb_problems;
     const int T = ws->nb_steps, n = env->dm_state, m = env->dm_act;
-    // candidates go to bank 0 (no wbank given) of the time-blocked planes, the reference is still the dense
-    // xref / uref (no ref_plane given)
-    const RolloutBanks rb{nullptr, opt->nb_alphas};
+    // candidates go, time-blocked, to bank 0; the reference is the dense xref / uref
+    const RolloutPlanes rp{0, 2 * opt->nb_alphas, nullptr};
     rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->K, ws->kff, ws->xref, ws->uref,
                         ws->weighting, opt->alphas, opt->nb_alphas, nullptr, ws->cand_state, ws->cand_action, nullptr,
-                        ws->cand_ret, ws->cand_finite, st, ws->gains_layout, 0, opt->nb_alphas, nullptr, nullptr, &rb);
+                        ws->cand_ret, ws->cand_finite, st, ws->gains_layout, 0, opt->nb_alphas, nullptr, nullptr, &rp);
     if (rc != TRAJOPT_OK) return rc;
-    // bank 0 of the double-buffered gains = the controller the reference was rolled out with (K / kff): the bank of
-    // ref_plane[p] then always holds the accepted gains of problem p, accepted iteration or not
-    if (ws->gains_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR) {   // banks interleaved per time step
-        const size_t wK = (size_t)n * m * NP * sizeof(double), wk = (size_t)m * NP * sizeof(double);
-        TRAJOPT_HIP_CHECK(hipMemcpy2DAsync(ws->cand_K, 2 * wK, ws->K, wK, wK, (size_t)T, hipMemcpyDeviceToDevice, st));
-        TRAJOPT_HIP_CHECK(hipMemcpy2DAsync(ws->cand_kff, 2 * wk, ws->kff, wk, wk, (size_t)T, hipMemcpyDeviceToDevice, st));
-    } else {                                                   // bank slowest
-        TRAJOPT_HIP_CHECK(hipMemcpyAsync(ws->cand_K, ws->K, (size_t)n * m * T * NP * sizeof(double), hipMemcpyDeviceToDevice, st));
-        TRAJOPT_HIP_CHECK(hipMemcpyAsync(ws->cand_kff, ws->kff, (size_t)m * T * NP * sizeof(double), hipMemcpyDeviceToDevice, st));
-    }
     DrvArgs a{*opt, *ws, n, m};
     const unsigned g1 = (unsigned)((NP + 255) / 256);
     const dim3 g2(g1, (unsigned)(T + 1));
     hipLaunchKernelGGL(init_select_kernel, dim3(g1), dim3(256), 0, st, a);
     hipLaunchKernelGGL(publish_kernel<true>, g2, dim3(256), 0, st, a, 0);   // xref / uref = the accepted rollout
-    // no finite rollout: the reference stays what xref / uref held, planted into plane 0
-    if (ws->gains_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR) hipLaunchKernelGGL(plant_kernel<true>, g2, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(plant_kernel<false>, g2, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(plant_finish_kernel, dim3(g1), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(published_kernel, dim3(g1), dim3(256), 0, st, a);
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
 }
@@ -459,19 +439,16 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
     if (opt->argmin_alpha || opt->nb_alphas < 2 || !ws->pending_list || !ws->pending_count) staged = false;
     // No copy on accept: the quadratisation reads the reference through ref_plane (time-blocked planes: whole 64-byte
     // runs per problem, whatever planes its neighbours read) and writes what it read through to the dense xref / uref,
-    // where the backward kernels' gradient norm and the rollout find it; candidates and gains go to bank wbank[p].
+    // where the backward kernels' gradient norm and the rollout find it; iteration `it` of this call writes its
+    // candidates into bank it % 2 and its gains into bank out_bank[p] (it % 2 for all but the rejecting problems).
     const RefView rv{ws->ref_plane, ws->cand_state, ws->cand_action, ws->xref, ws->uref};
-    const RolloutBanks rb{ws->wbank, opt->nb_alphas};
-    io.out_bank = ws->wbank;
-    if (nb_iter > 0) {   // a workspace that never saw trajopt_ilqr_init_rollout: its reference is still in xref / uref
-        if (gminor) hipLaunchKernelGGL(plant_kernel<true>, g2, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(plant_kernel<false>, g2, dim3(256), 0, st, a);
-        hipLaunchKernelGGL(plant_finish_kernel, dim3(g1), dim3(256), 0, st, a);
-    }
+    io.out_bank = ws->out_bank;
     for (int it = 0; it < nb_iter; ++it) {
         const int slot = (g_prof.on && g_prof.used < g_prof.cap) ? g_prof.used++ : -1;
+        const int wb = it & 1;
+        const RolloutPlanes rp{wb * opt->nb_alphas, 2 * opt->nb_alphas, ws->out_bank};
         prof_mark(st, slot, 0);
-        if (it == 0) hipLaunchKernelGGL(prep_kernel, dim3(g1), dim3(256), 0, st, a);   // later ones ride in select_kernel
+        if (it == 0) hipLaunchKernelGGL(prep_kernel, dim3(g1), dim3(256), 0, st, a, wb);   // later ones ride in select_kernel
         prof_mark(st, slot, 1);
         if (fused_qb) {
             // small batches of dx <= 4, du = 1 models: quadratisation and recursion in one launch, the expansion
@@ -490,30 +467,30 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         }
         if (!gminor) hipLaunchKernelGGL(gnorm_major_kernel, dim3((unsigned)NP), dim3(64), 0, st, a);
         prof_mark(st, slot, 3);
-        hipLaunchKernelGGL(post_backward_kernel, dim3(g1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(post_backward_kernel, dim3(g1), dim3(256), 0, st, a, wb);
         prof_mark(st, slot, 4);
         if (!staged) {
             rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
                                 ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                                 ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 0, opt->nb_alphas,
-                                nullptr, nullptr, &rb);
+                                nullptr, nullptr, &rp);
             if (rc != TRAJOPT_OK) return rc;
         } else {
             rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
                                 ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                                 ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 0, 1, nullptr, nullptr,
-                                &rb);
+                                &rp);
             if (rc != TRAJOPT_OK) return rc;
             TRAJOPT_HIP_CHECK(hipMemsetAsync(ws->pending_count, 0, sizeof(int32_t), st));
             hipLaunchKernelGGL(pending_kernel, dim3(g1), dim3(256), 0, st, a);
             rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
                                 ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                                 ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 1, opt->nb_alphas,
-                                ws->pending_list, ws->pending_count, &rb);
+                                ws->pending_list, ws->pending_count, &rp);
             if (rc != TRAJOPT_OK) return rc;
         }
         prof_mark(st, slot, 5);
-        hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a, it + 1 < nb_iter ? 1 : 0, staged ? 1 : 0);
+        hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a, it + 1 < nb_iter ? 1 : 0, staged ? 1 : 0, wb);
         if (opt->keep_value) {
             if (gminor) hipLaunchKernelGGL(promote_value_kernel<true>, g2, dim3(256), 0, st, a);
             else hipLaunchKernelGGL(promote_value_kernel<false>, g2, dim3(256), 0, st, a);
@@ -521,6 +498,7 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         if (it == nb_iter - 1) {   // xref / uref / K / kff of the accepted iterate, once per call
             if (gminor) hipLaunchKernelGGL(publish_kernel<true>, g2, dim3(256), 0, st, a, 1);
             else hipLaunchKernelGGL(publish_kernel<false>, g2, dim3(256), 0, st, a, 1);
+            hipLaunchKernelGGL(published_kernel, dim3(g1), dim3(256), 0, st, a);
         }
         prof_mark(st, slot, 6);
         // a failed launch is reported in the iteration it happens in, not after the remaining ones ran on its garbage

@@ -20,9 +20,9 @@
 // overlapped almost nothing - 0.42 ms, the same as the two separate launches - and raising the consumer's priority
 // starved the producer (0.61 ms).  One wave per SIMD doing both in turn runs at the pipe's rate: 0.26 ms.
 //
-// The producer part reads the reference trajectory through the driver's RefView (common.h): from candidate plane
-// ref_plane[p], no copy on accept; the actions it reads are written through to uref_out (first sweep only), the
-// array the rollout takes uref from.  The gains go to bank io.out_bank[p] of the double-buffered K / kff.
+// The producer part reads the reference trajectory through the driver's RefView (common.h): from the time-blocked
+// candidate plane ref_plane[p] - no copy on accept - or, ref_plane[p] < 0, from the dense xref / uref; what it reads
+// from a plane is written through to xref_out / uref_out (first sweep only), where the rollout takes it from.
 //
 // Used by trajopt_ilqr_iterate for envs with identity cost features (structured cost), PROBLEM_MINOR gains group,
 // gains-only outputs; everything else takes the two-kernel path.
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
     const bool in_r = r < (unsigned)N, in_c = c < (unsigned)N, in_rc = in_r && in_c;
     const bool skip = !c_exists || (io.active && io.active[cp] == 0);
     const unsigned cc = in_c ? c : 0u, rr = in_r ? r : 0u, cp8 = (unsigned)(cp * 8);
-    // gains: bank io.out_bank[cp] of the two interleaved per time step (trajopt_backward_io_t::out_bank)
-    const unsigned kmul = io.out_bank ? 2u : 1u, bank = c_exists ? (unsigned)gains_bank(io.out_bank, cp) : 0u;
+    // gains: bank io.out_bank[cp] of those interleaved per time step (trajopt_backward_io_t::out_bank)
+    const unsigned kmul = io.out_bank ? (unsigned)TRAJOPT_GAIN_BANKS : 1u, bank = c_exists ? (unsigned)gains_bank(io.out_bank, cp) : 0u;
     const unsigned o_c0 = (bank * N + cc) * np8 + cp8, o_z0 = bank * np8 + cp8;  // K[c], kff of slice 0
     const unsigned s_n = kmul * (unsigned)N * np8, s_1 = kmul * np8;
     const bool st_c = (N == 4) || in_c;
@@ -120,18 +120,19 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
     const bool p_livep = p_exists && !(io.active && io.active[pp] == 0);
     int p_sel = -1;
     if (a.rv.ref_plane && p_exists) p_sel = a.rv.ref_plane[pp];
-    // the driver: time-blocked candidate plane ref_plane[p] (common.h); otherwise the dense xref / uref
-    const bool refp = a.rv.ref_plane != nullptr;
-    const double* p_xsrc = refp ? a.rv.cand_state + (size_t)(p_sel >= 0 ? p_sel : 0) * tb_plane(N, T + 1, NP) : a.xref;
-    const double* p_usrc = refp ? a.rv.cand_action + (size_t)(p_sel >= 0 ? p_sel : 0) * tb_plane(M, T, NP) : a.uref;
+    // the driver: time-blocked candidate plane ref_plane[p] (common.h) when that is >= 0; otherwise the dense xref / uref
+    const bool refp = p_sel >= 0;   // per lane
+    const double* p_xsrc = refp ? a.rv.cand_state + (size_t)p_sel * tb_plane(N, T + 1, NP) : a.xref;
+    const double* p_usrc = refp ? a.rv.cand_action + (size_t)p_sel * tb_plane(M, T, NP) : a.uref;
     const double sc = e.cost_times_dt ? e.dt : 1.0;
     bool first_sweep = true;
     const __amdgpu_buffer_rsrc_t rK = f4_rsrc(io.K, (unsigned)((size_t)kmul * N * M * T * NP * 8));
     const __amdgpu_buffer_rsrc_t rkff = f4_rsrc(io.kff, (unsigned)((size_t)kmul * M * T * NP * 8));
     // uref_out: dropped stores (offset beyond the range) for the lanes with nothing to write through
     const bool through = a.rv.uref_out != nullptr && a.rv.xref_out != nullptr && refp && p_livep;
-    const __amdgpu_buffer_rsrc_t ruo = f4_rsrc(through ? a.rv.uref_out : io.kff, a.rv.uref_out ? (unsigned)((size_t)M * T * NP * 8) : 0u);
-    const __amdgpu_buffer_rsrc_t rxo = f4_rsrc(through ? a.rv.xref_out : io.kff, a.rv.xref_out ? (unsigned)((size_t)N * (T + 1) * NP * 8) : 0u);
+    const bool have_out = a.rv.uref_out != nullptr && a.rv.xref_out != nullptr;   // (wave-uniform: the descriptors are scalars)
+    const __amdgpu_buffer_rsrc_t ruo = f4_rsrc(have_out ? a.rv.uref_out : io.kff, have_out ? (unsigned)((size_t)M * T * NP * 8) : 0u);
+    const __amdgpu_buffer_rsrc_t rxo = f4_rsrc(have_out ? a.rv.xref_out : io.kff, have_out ? (unsigned)((size_t)N * (T + 1) * NP * 8) : 0u);
 
     for (;;) {  // sweeps: one, plus one per lambda retry (ilqr.py:162-173)
         bool alive = !frozen;
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
             // V[T] = w[T] diag(gxx), v[T] = cx[T] = w[T] gxx (y_T - g)
             const double wT = io.cost_w[T];
             const double VTerm = wT * dg;
-            const double xT = refp ? a.rv.cand_state[(size_t)(csel >= 0 ? csel : 0) * tb_plane(N, T + 1, NP) + tb_index(N, T, (int)rr, cp, NP)]
-                                   : a.xref[((size_t)N * T + rr) * NP + cp];
+            const double xT = csel >= 0 ? a.rv.cand_state[(size_t)csel * tb_plane(N, T + 1, NP) + tb_index(N, T, (int)rr, cp, NP)]
+                                        : a.xref[((size_t)N * T + rr) * NP + cp];
             double vterm = 0.0;
             if (wT != 0.0) {
                 const double y = ((e.periodic >> rr) & 1) ? wrap_angle(xT) : xT;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
             }
             vR = in_r ? vterm : 0.0;
             // x_T is not part of any chunk: written through here
-            if (first_sweep && a.rv.xref_out && refp && c == 0 && in_r && !skip) a.rv.xref_out[((size_t)N * T + rr) * NP + cp] = xT;
+            if (first_sweep && a.rv.xref_out && csel >= 0 && c == 0 && in_r && !skip) a.rv.xref_out[((size_t)N * T + rr) * NP + cp] = xT;
             VT = f4_mm(VTerm, eye, 0.0);
         }
 
@@ -393,7 +394,8 @@ bool fused_qb4_supported(const trajopt_env_t* env, int T, int64_t NP) {
     if (env->model != TRAJOPT_ENV_PENDULUM && env->model != TRAJOPT_ENV_CARTPOLE) return false;
     if (env->nb_features != 0 || NP > 6144) return false;
     const int n = env->dm_state;
-    return (double)(T + 2) * n * n * (double)NP * 8.0 < 4294967296.0;
+    return (double)(T + 2) * n * n * (double)NP * 8.0 < 4294967296.0 &&
+           (double)TRAJOPT_GAIN_BANKS * (T + 1) * n * (double)NP * 8.0 < 4294967296.0;
 }
 
 // io: as for trajopt_ilqr_backward_pass_batched with the structured cost set (cost_w, cost_gxx, cost_guu) and

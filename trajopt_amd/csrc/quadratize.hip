@@ -24,8 +24,9 @@ struct QuadArgs {
     size_t NP;
     int T, convention;
     // Driver only (no copy on accept, RefView in common.h): with `ref_plane` non-NULL problem p reads its reference
-    // trajectory from the time-blocked candidate plane ref_plane[p] and writes what it read through to xref_out /
-    // uref_out - the dense arrays the backward pass (gradient norm, ilqr.py:176) and the rollout take it from.
+    // trajectory from the time-blocked candidate plane ref_plane[p] (>= 0; else from the dense xref / uref) and writes
+    // what it read from a plane through to xref_out / uref_out - the dense arrays the backward pass (gradient norm,
+    // ilqr.py:176) and the rollout take it from.
     const int32_t* ref_plane;
     const double *cand_state, *cand_action;
     double *xref_out, *uref_out;
@@ -52,8 +53,8 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
 
     double x[N], u[M], ul[M];
     bool through = false;
-    if (a.ref_plane) {   // the driver: time-blocked candidate plane ref_plane[p] (common.h)
-        const int k = a.ref_plane[p] >= 0 ? a.ref_plane[p] : 0;
+    const int k = a.ref_plane ? a.ref_plane[p] : -1;
+    if (k >= 0) {   // the driver: time-blocked candidate plane ref_plane[p] (common.h)
         const double* xs = a.cand_state + (size_t)k * tb_plane(n, T + 1, NP);
         const double* us = a.cand_action + (size_t)k * tb_plane(m, T, NP);
 #pragma unroll

@@ -28,14 +28,15 @@ struct RolloutArgs {
     int alpha_begin;
     const int32_t* plist;
     const int32_t* pcount;
-    // Driver only (RolloutBanks in common.h; NULL / 0 otherwise): state / action are the driver's TIME-BLOCKED
-    // candidate planes, `planes` per bank; problem p writes bank wbank[p] (bank 0 without wbank) and reads the gains
-    // from that bank of the double-buffered K / kff (layout: trajopt_backward_io_t::out_bank).
-    const int32_t* wbank;
-    int planes;
+    // Driver only (RolloutPlanes in common.h): state / action are the driver's TIME-BLOCKED candidate planes; alpha ai
+    // goes to plane first_plane + ai, the lanes of stopped problems to junk_plane.
+    int first_plane, junk_plane;
+    // ... and the gains K / kff hold TRAJOPT_GAIN_BANKS banks, of which problem p reads bank out_bank[p] (layout:
+    // trajopt_backward_io_t::out_bank); NULL: plain arrays
+    const int32_t* out_bank;
 };
 
-// index into the gains K / kff, which hold kmul = 2 banks when the driver double-buffers them
+// index into the gains K / kff, which hold kmul banks when the driver multi-buffers them
 template <bool KMINOR>
 __device__ __forceinline__ size_t gk(size_t eps, size_t slices, int t, size_t e, size_t p, size_t NP, int kmul, int bank) {
     return KMINOR ? (eps * (size_t)(kmul * t + bank) + e) * NP + p
@@ -136,9 +137,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     }
     // A lane with nothing to do (beyond the batch, or a stopped problem) leaves at once - except under TB, where the
     // whole wave writes the staged blocks out together: there it runs along on its own problem's data (beyond the
-    // batch: as a duplicate of the first lane of the grid, same values to the same addresses) and writes its candidates
-    // like the others - into the bank a stopped problem never reads again - but not its return; a wave without any
-    // live lane still leaves as a whole.
+    // batch: problem 0's) and writes its candidates like the others, but into a plane of their own that nobody
+    // reads, and not its return; a wave without any live lane still leaves as a whole.
     const bool live = !idle && !(a.active && a.active[p] == 0);
     if constexpr (TB) {
         if (__builtin_amdgcn_ballot_w64(live) == 0) return;
@@ -164,9 +164,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     const int n = SYS::n(e), m = SYS::m(e), T = a.T;
     const double alpha = a.alphas[ai];
     const size_t En1 = (size_t)n * (T + 1), En = (size_t)n * T, Em = (size_t)m * T, Enm = (size_t)n * m * T;
-    const int kmul = a.wbank ? 2 : 1, bank = a.wbank ? (a.wbank[p] & 1) : 0;
-    // candidate planes: alpha slowest, inside the problem's bank
-    const size_t plane = (size_t)bank * a.planes + ai;
+    const int kmul = a.out_bank ? TRAJOPT_GAIN_BANKS : 1, bank = gains_bank(a.out_bank, p);
+    // candidate planes: alpha slowest (TB: inside this iteration's bank; a lane without a result of its own writes junk_plane)
+    const size_t plane = TB ? (size_t)(live ? a.first_plane + ai : a.junk_plane) : (size_t)ai;
     double* st = (!TB && a.state) ? a.state + plane * En1 * NP : nullptr;
     double* ac = (!TB && a.action) ? a.action + plane * Em * NP : nullptr;
     double* co = a.cost ? a.cost + (size_t)ai * (size_t)(T + 1) * NP : nullptr;
@@ -443,8 +443,8 @@ struct RolloutLaunch {
         const dim3 grid((unsigned)((total + 63) / 64)), block(64);
         const bool mi = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR, kmi = k_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
         // (FAST addresses the gains with 32-bit per-lane byte offsets)
-        const double kbytes = (a.wbank ? 2.0 : 1.0) * (kmi ? (double)SYS::N * SYS::M * (double)a.NP * 8.0
-                                                           : (double)a.NP * SYS::N * SYS::M * (double)a.T * 8.0);
+        const double kbytes = (a.out_bank ? (double)TRAJOPT_GAIN_BANKS : 1.0) * (kmi ? (double)SYS::N * SYS::M * (double)a.NP * 8.0
+                                                                                     : (double)a.NP * SYS::N * SYS::M * (double)a.T * 8.0);
         const bool fast = SYS::kStatic && a.state && a.action && !a.cost && !a.env.slew_rate && a.env.periodic == 0 &&
                           !a.env.cost_times_dt && a.env.nb_features == 0 && a.T > 0 && kbytes + (double)a.NP * 8.0 < 4294967296.0;
         if constexpr (SYS::kStatic) {
@@ -481,13 +481,14 @@ int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, cons
                    const double* kff, const double* xref, const double* uref, const double* weighting,
                    const double* alphas_host, int nb_alphas, const int32_t* active, double* state, double* action,
                    double* cost, double* ret, int32_t* finite, hipStream_t st, int k_layout, int alpha_begin,
-                   int alpha_end, const int32_t* plist, const int32_t* pcount, const RolloutBanks* banks) {
+                   int alpha_end, const int32_t* plist, const int32_t* pcount, const RolloutPlanes* planes) {
     if (alpha_begin < 0 || alpha_end > nb_alphas || alpha_begin >= alpha_end) return TRAJOPT_ERR_BAD_ARG;
-    if (banks && (layout != TRAJOPT_LAYOUT_PROBLEM_MINOR || !state || !action)) return TRAJOPT_ERR_BAD_ARG;
+    if (planes && (layout != TRAJOPT_LAYOUT_PROBLEM_MINOR || !state || !action)) return TRAJOPT_ERR_BAD_ARG;
     RolloutLaunch L;
     L.a.alpha_begin = alpha_begin; L.a.plist = plist; L.a.pcount = pcount;
-    L.a.wbank = banks ? banks->wbank : nullptr; L.a.planes = banks ? banks->planes : 0;
-    L.tb = banks != nullptr;
+    L.a.first_plane = planes ? planes->first_plane : 0; L.a.junk_plane = planes ? planes->junk_plane : 0;
+    L.a.out_bank = planes ? planes->out_bank : nullptr;
+    L.tb = planes != nullptr;
     nb_alphas = alpha_end;  // the kernel runs alphas [alpha_begin, alpha_end)
     L.a.env = *env;
     L.a.x0 = x0; L.a.K = K; L.a.kff = kff; L.a.xref = xref; L.a.uref = uref; L.a.weighting = weighting;

@@ -113,20 +113,21 @@ class BatchedILQR:
         self._A, self._B = zg(n, n, T), zg(n, m, T)
         self._Cxx, self._cx = zg(n, n, T + 1), zg(n, T + 1)
         self._Cuu, self._cu, self._Cxu = zg(m, m, T + 1), zg(m, T + 1), zg(n, m, T + 1)
-        # candidate gains, two banks (include/trajopt_amd.h, trajopt_backward_io_t::out_bank): an accept flips the
-        # problem's bank instead of copying - PROBLEM_MINOR (T, 2, n, m, N), PROBLEM_MAJOR (2, N, T, n, m)
+        # candidate gains, three banks (include/trajopt_amd.h, trajopt_backward_io_t::out_bank): an accept records the
+        # bank instead of copying - PROBLEM_MINOR (T, 3, n, m, N), PROBLEM_MAJOR (3, N, T, n, m)
         if GL == LAYOUT_PROBLEM_MINOR:
-            self._cand_K, self._cand_kff = z(T, 2, n, m, N), z(T, 2, m, N)
+            self._cand_K, self._cand_kff = z(T, 3, n, m, N), z(T, 3, m, N)
         else:
-            self._cand_K, self._cand_kff = z(2, N, T, n, m), z(2, N, T, m)
+            self._cand_K, self._cand_kff = z(3, N, T, n, m), z(3, N, T, m)
         # dV = [kff'qu, 1/2 kff'Quu kff] per problem belongs to the gains group: (2, N) for PROBLEM_MINOR, (N, 2) for MAJOR
         self._dV, self._g_norm = (z(2, N) if GL == LAYOUT_PROBLEM_MINOR else z(N, 2)), z(N)
         self._diverge, self._active, self._sel = torch.zeros(N, **i32), torch.zeros(N, **i32), torch.zeros(N, **i32)
-        # candidates of every alpha, two banks of `na` planes; the reference of problem p is plane _ref_plane[p]
-        # (< 0: xref / uref), the next iteration writes bank _wbank[p]
-        # planes are time-blocked, (block of 8 steps, row, N, step in block): csrc/common.h
-        self._cand_state, self._cand_action = z(2 * na, (T + 8) // 8, n, N, 8), z(2 * na, (T + 7) // 8, m, N, 8)
-        self._ref_plane, self._wbank = torch.full((N,), -1, **i32), torch.zeros(N, **i32)
+        # candidates of every alpha: two banks of `na` planes + one plane nobody reads; the reference of problem p is
+        # plane _ref_plane[p] (< 0: xref / uref), its accepted gains are bank _gains_bank[p] (< 0: K / kff).
+        # Planes are time-blocked, (block of 8 steps, row, N, step in block): csrc/common.h
+        self._cand_state, self._cand_action = z(2 * na + 1, (T + 8) // 8, n, N, 8), z(2 * na + 1, (T + 7) // 8, m, N, 8)
+        self._ref_plane, self._gains_bank = torch.full((N,), -1, **i32), torch.full((N,), -1, **i32)
+        self._out_bank = torch.zeros(N, **i32)
         self._cand_ret, self._cand_finite = z(na, N), torch.zeros((na, N), **i32)
         self._pending_list, self._pending_count = torch.zeros(N, **i32), torch.zeros(1, **i32)
         if self.keep_value:
@@ -185,8 +186,8 @@ class BatchedILQR:
         self.trace_len.zero_()
         self._trace_bound = 0
         self._initialised = False
-        self._ref_plane.fill_(-1)   # the reference is xref / uref again until init_rollout
-        self._wbank.zero_()
+        self._ref_plane.fill_(-1)   # reference and controller are the dense xref / uref / K / kff again
+        self._gains_bank.fill_(-1)
 
     def _reserve_trace(self, nb_iter):
         """The device appends one return per accepted iteration (ilqr.py:219) and drops what does not fit: make room
@@ -211,7 +212,7 @@ class BatchedILQR:
             setattr(w, k, dptr(getattr(self, k)))
         for k in ("A", "B", "Cxx", "cx", "Cuu", "cu", "Cxu", "cand_K", "cand_kff", "dV", "g_norm", "diverge", "active",
                   "sel", "cand_state", "cand_action", "cand_ret", "cand_finite", "pending_list", "pending_count", "ref_plane",
-                  "wbank"):
+                  "gains_bank", "out_bank"):
             setattr(w, k, dptr(getattr(self, "_" + k)))
         if self.keep_value:
             for k in ("V", "v", "Qxx", "Qux", "Quu", "qx", "qu"):
