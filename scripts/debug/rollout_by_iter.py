@@ -16,7 +16,6 @@ for it in range(int(os.environ.get("ITERS", 16))):
     _lib.check(L.trajopt_profile_begin(1)); s.iterate(1); torch.cuda.synchronize()
     ms = (C.c_double * 6)(); n = C.c_int(0)
     _lib.check(L.trajopt_profile_end(ms, C.byref(n)))
-    ref = s._ref_plane.cpu().numpy(); wb = s._wbank.cpu().numpy()
-    runs = int((np.diff(ref) != 0).sum()) + 1
+    ob = s._out_bank.cpu().numpy(); sel = s._sel.cpu().numpy()
     print(it, {k: round(ms[i], 3) for i, k in enumerate(PHASES) if k in ("backward", "quadratize", "rollout", "select_commit")},
-          "planes", np.bincount(ref[ref >= 0], minlength=22).tolist(), "runs of equal plane", runs, "wbank1", int(wb.sum()))
+          "accepted alpha", np.bincount(sel[sel >= 0], minlength=11).tolist(), "rejected", int((sel < 0).sum()), "out_bank", np.bincount(ob, minlength=3).tolist())

@@ -31,6 +31,7 @@ struct RolloutArgs {
     // Driver only (RolloutPlanes in common.h): state / action are the driver's TIME-BLOCKED candidate planes; alpha ai
     // goes to plane first_plane + ai, the lanes of stopped problems to junk_plane.
     int first_plane, junk_plane;
+    int xcd_tiles;   // 1: workgroup -> (tile of 64 problems, alpha) mapping that keeps a tile's alphas on one XCD
     // ... and the gains K / kff hold TRAJOPT_GAIN_BANKS banks, of which problem p reads bank out_bank[p] (layout:
     // trajopt_backward_io_t::out_bank); NULL: plain arrays
     const int32_t* out_bank;
@@ -96,7 +97,10 @@ __device__ __forceinline__ void tb_flush(const TbStage<ROWS>& sg, const unsigned
 // no angle wrapping, no dt scaling) - with the stores unconditional: a store under a (wave-uniform) `if (pointer)` makes the waitcnt pass wait for EVERY outstanding
 // memory operation (vmcnt(0)) before the prefetched gains are used, i.e. for this step's stores to be acknowledged.
 // TB: state / action are the driver's time-blocked candidate planes, written through the LDS stage above.
-template <class SYS, bool MINOR, bool KMINOR, bool FAST, bool TB>
+// UNR (with FAST and TB): the 8 steps of a block are straight-line code.  That is the fastest form for a lone wave per
+// SIMD (no wait at all for a block's write-out), but it takes 256 registers and more, i.e. one wave per SIMD; batches
+// that oversubscribe the chip take the rolled form (two waves per SIMD hide its one wait per block).
+template <class SYS, bool MINOR, bool KMINOR, bool FAST, bool TB, bool UNR>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     constexpr int N = SYS::N, M = SYS::M;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,7 +109,18 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     size_t p;
     int ai;
     bool idle = false;  // no early return before the barrier below
-    if (a.plist) {
+    if (a.xcd_tiles) {
+        // The driver's order: the nA step sizes of a tile of 64 problems are consecutive workgroups OF ONE XCD
+        // (workgroups b and b + 8 share one, cdna guide): they run at about the same time and read the tile's gains
+        // and reference through one L2, where the plain order - alpha slowest - fetches them from HBM once per alpha.
+        const unsigned nA = (unsigned)(a.nb_alphas - a.alpha_begin);
+        const unsigned b = blockIdx.x, j = b >> 3;
+        const size_t q = ((size_t)(j / nA) * 8 + (b & 7u)) * 64 + lane;   // index into the problems (or the list)
+        const size_t cnt = a.plist ? (size_t)*a.pcount : NP;
+        idle = q >= cnt;
+        p = idle ? 0 : (a.plist ? (size_t)a.plist[q] : q);
+        ai = a.alpha_begin + (int)(j % nA);
+    } else if (a.plist) {
         const size_t cnt = (size_t)*a.pcount;
         idle = idx >= cnt * (size_t)(a.nb_alphas - a.alpha_begin);
         p = idle ? 0 : (size_t)a.plist[idx % (cnt ? cnt : 1)];
@@ -252,6 +267,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         // is then refilled IN PLACE with the inputs of the step after next.  Two steps of distance matter because
         // loads and stores retire through one in-order counter: a load issued behind the write-out of a block is only
         // seen to have arrived once those 40 stores have been acknowledged.
+        // (kAhead2: for the lone-wave forms.  Where several waves share a SIMD they hide that wait for each other, and
+        // the plain one-step-ahead prefetch into the other register set needs fewer registers - an occupancy step for dx = 6.)
+        constexpr bool kAhead2 = !TB || UNR;
         auto step = [&](In& s, auto put_next_c) {
             constexpr bool put_next = decltype(put_next_c)::value;
             double u[M];  // u = clip(uref + alpha kff + K (x - xref))    objects.py:137-139, ilqr.py:97
@@ -263,7 +281,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 u[j] = clip_g(fma(alpha, s.kf[j], s.ur[j]) + kx, e.umax[j]);
             }
             total += env_cost_plain<N, M>(e, x, u, s.w);  // ilqr.py:98 passes u_last = u_t
-            load(s);
+            if constexpr (kAhead2) load(s);
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 if constexpr (TB) put_u(t, j, u[j]);
@@ -281,7 +299,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         };
         In sa, sb;
         load(sa);
-        load(sb);
+        if constexpr (kAhead2) load(sb);
         if constexpr (TB) {
             // Whole blocks: 8 steps, then both blocks go out - unconditional code in a loop with one entry state.  As
             // many stores are put behind the first load as a block's write-out puts behind every later one (block 0 as
@@ -291,12 +309,32 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
             flush_block(0);
             const int nblk = T / kTB;
             for (int b = 0; b < nblk; ++b) {
+                if constexpr (UNR) {
 #pragma unroll
-                for (int k = 0; k < kTB / 2; ++k) {
+                    for (int k = 0; k < kTB / 2; ++k) {
+                        if constexpr (!kAhead2) load(sb);
+                        step(sa, std::true_type{});
+                        ++t;
+                        if constexpr (!kAhead2) load(sa);
+                        if (k + 1 < kTB / 2) step(sb, std::true_type{});
+                        else step(sb, std::false_type{});
+                        ++t;
+                    }
+                } else {
+#pragma unroll 1
+                    for (int k = 0; k < kTB / 2 - 1; ++k) {
+                        if constexpr (!kAhead2) load(sb);
+                        step(sa, std::true_type{});
+                        ++t;
+                        if constexpr (!kAhead2) load(sa);
+                        step(sb, std::true_type{});
+                        ++t;
+                    }
+                    if constexpr (!kAhead2) load(sb);
                     step(sa, std::true_type{});
                     ++t;
-                    if (k + 1 < kTB / 2) step(sb, std::true_type{});
-                    else step(sb, std::false_type{});
+                    if constexpr (!kAhead2) load(sa);
+                    step(sb, std::false_type{});
                     ++t;
                 }
                 flush_block(b);
@@ -304,16 +342,20 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 for (int i = 0; i < N; ++i) put_x(t, i, x[i]);   // slice 8 b + 8 = slot 0 of the next block
             }
             while (t < T) {   // the last, partial block: fewer than 8 steps
+                if constexpr (!kAhead2) load(sb);
                 step(sa, std::true_type{});
                 if (++t >= T) break;
+                if constexpr (!kAhead2) load(sa);
                 step(sb, std::true_type{});
                 ++t;
             }
             flush_tail();
         } else {
             while (t < T) {
+                if constexpr (!kAhead2) load(sb);
                 step(sa, std::true_type{});
                 if (++t >= T) break;
+                if constexpr (!kAhead2) load(sa);
                 step(sb, std::true_type{});
                 ++t;
             }
@@ -440,7 +482,8 @@ struct RolloutLaunch {
     template <class SYS>
     void operator()() {
         const size_t total = a.NP * (size_t)(a.nb_alphas - a.alpha_begin);
-        const dim3 grid((unsigned)((total + 63) / 64)), block(64);
+        const size_t tiles8 = (a.NP + 511) / 512;   // tiles of 64 problems, rounded up to a multiple of 8 (one per XCD)
+        const dim3 grid((unsigned)(a.xcd_tiles ? tiles8 * 8 * (size_t)(a.nb_alphas - a.alpha_begin) : (total + 63) / 64)), block(64);
         const bool mi = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR, kmi = k_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
         // (FAST addresses the gains with 32-bit per-lane byte offsets)
         const double kbytes = (a.out_bank ? (double)TRAJOPT_GAIN_BANKS : 1.0) * (kmi ? (double)SYS::N * SYS::M * (double)a.NP * 8.0
@@ -449,19 +492,25 @@ struct RolloutLaunch {
                           !a.env.cost_times_dt && a.env.nb_features == 0 && a.T > 0 && kbytes + (double)a.NP * 8.0 < 4294967296.0;
         if constexpr (SYS::kStatic) {
             if (mi && fast) {
-                if (tb && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, true>), grid, block, 0, st, a);
-                else if (tb) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, true>), grid, block, 0, st, a);
-                else if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, false>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, false>), grid, block, 0, st, a);
+                // straight-line blocks while every wave has a SIMD to itself (and the model's registers allow it)
+                // (tried for dx + du >= 6, where the stage's LDS allows one wave per SIMD anyway: 8192 double cartpoles
+                // 1.90 ms against 1.81 rolled)
+                const bool unr = total <= 64 * 1024 && SYS::N + SYS::M <= 7;
+                if (tb && unr && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, true, true>), grid, block, 0, st, a);
+                else if (tb && unr) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, true, true>), grid, block, 0, st, a);
+                else if (tb && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, true, false>), grid, block, 0, st, a);
+                else if (tb) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, true, false>), grid, block, 0, st, a);
+                else if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, false, false>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, false, false>), grid, block, 0, st, a);
                 return;
             }
         }
-        if (tb && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false, true>), grid, block, 0, st, a);   // (tb: mi)
-        else if (tb) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, false, true>), grid, block, 0, st, a);
-        else if (mi && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false, false>), grid, block, 0, st, a);
-        else if (mi) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, false, false>), grid, block, 0, st, a);
-        else if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, false, true, false, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((rollout_kernel<SYS, false, false, false, false>), grid, block, 0, st, a);
+        if (tb && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false, true, false>), grid, block, 0, st, a);   // (tb: mi)
+        else if (tb) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, false, true, false>), grid, block, 0, st, a);
+        else if (mi && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false, false, false>), grid, block, 0, st, a);
+        else if (mi) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, false, false, false>), grid, block, 0, st, a);
+        else if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, false, true, false, false, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((rollout_kernel<SYS, false, false, false, false, false>), grid, block, 0, st, a);
     }
 };
 
@@ -488,6 +537,8 @@ int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, cons
     L.a.alpha_begin = alpha_begin; L.a.plist = plist; L.a.pcount = pcount;
     L.a.first_plane = planes ? planes->first_plane : 0; L.a.junk_plane = planes ? planes->junk_plane : 0;
     L.a.out_bank = planes ? planes->out_bank : nullptr;
+    // (only where the chip is oversubscribed: measured on 4096 cartpoles x 11 alphas, 704 waves, the plain order is 5 % faster)
+    L.a.xcd_tiles = (planes && (double)NP * (alpha_end - alpha_begin) > 65536.0) ? 1 : 0;
     L.tb = planes != nullptr;
     nb_alphas = alpha_end;  // the kernel runs alphas [alpha_begin, alpha_end)
     L.a.env = *env;
