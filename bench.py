@@ -30,12 +30,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+# fp64 VECTOR peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s (AMD's MI355X figure; the guide
+# lists matrix-core peaks only).  The rollout issues plain v_fma_f64 / v_mul_f64 / v_add_f64: this is its ceiling.
+FP64_VALU_PEAK_TFLOPS = 78.6
 PHASES = ("prep", "quadratize", "backward", "post_backward", "rollout", "select_commit")
 
 
 def alg_bytes_per_problem_step(n, m, nb_alphas):
-    """ALGORITHMIC HBM bytes per problem-timestep of each kernel (fp64; every array touched once).
-    backward: SURVEY 8(d) gains-only form.  quadratize: reads xref, uref; writes A, B, Cxx, cx, Cuu, cu, Cxu.
+    """ALGORITHMIC HBM bytes per problem-timestep of each kernel (fp64; every array touched once), SURVEY 8(d).
+    backward: gains-only form, dense inputs.  quadratize: reads xref, uref; writes A, B, Cxx, cx, Cuu, cu, Cxu.
     rollout: reads K, kff, xref, uref once; writes the state/action of ONE (the accepted) candidate - the other
     candidates' stores are a design cost of the parallel line search, not algorithmic bytes."""
     return {
@@ -44,6 +47,31 @@ def alg_bytes_per_problem_step(n, m, nb_alphas):
         "rollout": 8 * (n * m + 2 * m + n) + 8 * (n + m),
         "select_commit": 2 * 8 * (n + m + n * m + m),
     }
+
+
+def moved_bytes_per_problem_step(n, m, plan):
+    """Bytes the LAUNCHED variant of each phase moves per problem-timestep (what `frac` of the HBM roofline is based
+    on; the structured cost and the fused kernel skip most of the dense algorithmic bytes above).
+    fused quadratise + backward: reads x, u through ref_plane, writes them through to xref / uref, writes K, kff.
+    structured two-kernel path: quadratise reads x, u, writes A, B, cx, cu (+ x, u through); backward reads A, B, cx,
+    cu, uref, writes K, kff.  dense: the algorithmic bytes."""
+    xu, gains = 8 * (n + m), 8 * (n * m + m)
+    if plan["fused_quad_bwd"]:
+        return {"backward": 2 * xu + gains, "quadratize": 0}
+    if plan["structured_cost"]:
+        lin = 8 * (n * n + n * m + n + m)
+        return {"backward": lin + 8 * m + gains, "quadratize": 2 * xu + lin}
+    a = alg_bytes_per_problem_step(n, m, 0)
+    return {"backward": a["backward"], "quadratize": a["quadratize"] + xu}
+
+
+def stamped(path, stamp):
+    """JSON kept under profiles/ if it was made from the current kernel sources (its "stamp"), else None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", path)))
+    except (OSError, ValueError):
+        return None
+    return d if d.get("stamp") == stamp else None
 
 
 def make_problem_set(env, N, T, seed):
@@ -207,19 +235,40 @@ def main():
 
     if rank == 0:
         ab = alg_bytes_per_problem_step(n, m, nb_alphas)
-        per_launch = ab[dom] * N * T
-        achieved = per_launch / (dom_ms * 1e-3) / 1e9
-        bwd_gbs = ab["backward"] * N * T / (phases["backward"] * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
-        # separate runs, gfx950 read correction applied; profiles/r01_c_pmc_traffic_c2.json) - PMC counters cannot
-        # be sampled from inside this process, so it is only filled for the workload they were collected on
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic_c2.json")))
-            if a.env == "cartpole" and N == 4096 and T == 500 and nb_alphas == 11:
-                traffic = pmc["by_phase"].get(dom)
-        except (OSError, ValueError, KeyError):
-            traffic = None
+        plan = solver.plan()
+        mb = moved_bytes_per_problem_step(n, m, plan)
+        stamp = _lib.source_stamp()
+        is_c2 = a.env == "cartpole" and N == 4096 and T == 500 and nb_alphas == 11
+        tag = {("cartpole", 4096, 500): "C2", ("double_cartpole", 8192, 500): "C3 (one GPU's share)",
+               ("quadrotor", 4096, 500): "C4", ("pendulum", 1, 100): "C1"}.get((a.env, N, T), "custom")
+        # HBM traffic / issue counters of the kernels from the committed rocprofv3 --pmc passes (separate runs, gfx950
+        # read correction applied: scripts/pmc_traffic.py, scripts/pmc_sq.py) - PMC counters cannot be sampled from
+        # inside this process, so they are quoted only for the workload they were collected on AND only while the
+        # kernel sources are the ones they were collected from (stamp)
+        pmc = stamped("r02_pmc_traffic_c2.json", stamp) if is_c2 else None
+        sq = stamped("r02_pmc_sq_c2.json", stamp) if is_c2 else None
+        census = stamped("r02_rollout_isa_census.json", stamp)
+        traffic = pmc["by_phase"].get(dom) if pmc else None
+        hbm_alg = ab[dom] * N * T / (dom_ms * 1e-3) / 1e9
+        if dom == "rollout" and census and a.env in census["kernels"] and plan["rollout_straight_line"]:
+            # the rollout is a chain of plain fp64 vector instructions: priced against the fp64 VALU peak, with the
+            # flops of one step counted in the kernel's ISA (profiles/r02_rollout_isa_census.json)
+            fl = census["kernels"][a.env]["fp64_flops_per_lane_step"]
+            achieved = fl * N * nb_alphas * T / (dom_ms * 1e-3) / 1e12
+            roof = {"bound": "fp64-valu", "kernel": dom, "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+                    "fp64_flops_per_lane_step": fl, "instructions_per_step": census["kernels"][a.env]["instructions_per_step"],
+                    "lanes": N * nb_alphas, "waves_per_simd": N * nb_alphas / 64.0 / 1024.0,
+                    "hbm_algorithmic_GBps": hbm_alg, "hbm_frac": hbm_alg / HBM_PEAK_GBS,
+                    "alg_bytes_per_launch": ab[dom] * N * T, "avg_launch_ms": dom_ms,
+                    "valu_insts_per_simd_cycle_pmc": (sq["kernels_by_phase"].get(dom, {}).get("valu_insts_per_simd_cycle") if sq else None)}
+        else:
+            moved = mb.get(dom, ab[dom]) * N * T
+            achieved = moved / (dom_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "moved_bytes_per_launch": moved,
+                    "alg_bytes_per_launch": ab[dom] * N * T, "avg_launch_ms": dom_ms}
+        bwd_moved = mb["backward"] * N * T / (phases["backward"] * 1e-3) / 1e9
         out = {
             "metric": "problem-timesteps/sec (iLQR iteration, batched)",
             "value": world * N * T * K / elapsed,
@@ -228,16 +277,19 @@ def main():
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: batched iLQR %s dx=%d du=%d T=%d, %d instances per GPU, %d alphas, reg=1, "
-                                   "stopping rules disabled" % (a.env, n, m, T, N, nb_alphas),
+            "config": {"workload": "%s: batched iLQR %s dx=%d du=%d T=%d, %d instances per GPU, %d alphas, reg=1, "
+                                   "stopping rules disabled" % (tag, a.env, n, m, T, N, nb_alphas),
                        "instances_per_gpu": N, "horizon": T, "parallelism": "problems sharded x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_per_launch": per_launch, "avg_launch_ms": dom_ms},
+            "roofline": roof,
             "phase_ms": phases,
             "phase_ms_note": "six-phase breakdown: %d iterations bracketed after the timed region; the timed region "
                              "carries only the dominant kernel's two events per iteration" % KB,
-            "backward_pass_GBps": bwd_gbs,
+            "plan": plan,
+            "backward_pass": {"moved_bytes_per_problem_step": mb["backward"], "GBps_moved": bwd_moved,
+                              "frac_of_hbm_peak": bwd_moved / HBM_PEAK_GBS,
+                              "dense_algorithmic_bytes_per_problem_step": ab["backward"],
+                              "note": "quadratise + backward in one launch" if plan["fused_quad_bwd"] else "backward kernel alone"},
+            "source_stamp": stamp,
             "mean_return": float(ret.mean()),
         }
         if not a.no_cpu_baseline:

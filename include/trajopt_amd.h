@@ -435,6 +435,8 @@ typedef struct trajopt_ilqr_plan {
     int32_t fused_quad_bwd;    /* 1: quadratisation and backward pass are one launch (fused_qb4.hip)                   */
     int32_t staged_line_search;/* 1: alphas[0] for everybody, the rest for the compacted list of rejecting problems   */
     int32_t backward_kernel;   /* TRAJOPT_KERNEL_* family of the backward pass                                         */
+    int32_t rollout_straight_line; /* 1: the rollout's lone-wave form (8 steps of straight-line code per block)        */
+    int32_t pad_;
 } trajopt_ilqr_plan_t;
 int trajopt_ilqr_plan(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt, const trajopt_ilqr_workspace_t* ws,
                       trajopt_ilqr_plan_t* plan);

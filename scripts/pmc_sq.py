@@ -7,8 +7,12 @@ SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE (MI355X_MICROARCH.md:
 SQ_ACTIVE_INST_* count quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs)."""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from trajopt_amd import _lib  # noqa: E402  (source_stamp only)
 
 
 def main():
@@ -33,8 +37,15 @@ def main():
             d["gpu_cycles"] = cyc
             d["valu_insts_per_simd_cycle"] = d["SQ_INSTS_VALU"] / (cyc * 1024.0)
         res[k] = d
-    json.dump({"workload": workload, "units": "means per launch; SQ_* summed over all SIMDs/XCDs", "kernels": res},
-              open(out, "w"), indent=1)
+    by_phase = {}
+    for k, d in res.items():
+        for ph, tag in (("rollout", "rollout_kernel"), ("quadratize", "quadratize_kernel"), ("backward", "bwd_"),
+                        ("backward", "fused_qb4_kernel")):
+            if tag in k and d.get("launches", 0) >= by_phase.get(ph, {}).get("launches", 0):
+                by_phase[ph] = d
+    json.dump({"stamp": _lib.source_stamp(), "workload": workload,
+               "units": "means per launch; SQ_* summed over all SIMDs/XCDs", "kernels": res,
+               "kernels_by_phase": by_phase}, open(out, "w"), indent=1)
     for k, d in res.items():
         print(k, json.dumps({c: round(v, 3) for c, v in d.items()}))
 

@@ -6,8 +6,12 @@ section prescribes) into per-kernel HBM bytes per launch -> profiles/*_pmc_traff
 """
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from trajopt_amd import _lib  # noqa: E402  (source_stamp only)
 
 
 def per_kernel(path, counter):
@@ -34,10 +38,11 @@ def main():
                       "hbm_bytes": 2.0 * f.get(k, 0.0) + w.get(k, 0.0)}
     phase = {}
     for k, v in kernels.items():
-        for ph, tag in (("rollout", "rollout_kernel"), ("quadratize", "quadratize_kernel"), ("backward", "bwd_")):
+        for ph, tag in (("rollout", "rollout_kernel"), ("quadratize", "quadratize_kernel"), ("backward", "bwd_"),
+                        ("backward", "fused_qb4_kernel"), ("select_commit", "select_kernel"), ("select_commit", "publish_kernel")):
             if tag in k:
                 phase[ph] = phase.get(ph, 0.0) + v["hbm_bytes"]
-    json.dump({"units": "bytes per launch (mean over the run's launches); FETCH_SIZE/WRITE_SIZE are reported in KiB by "
+    json.dump({"stamp": _lib.source_stamp(), "units": "bytes per launch (mean over the run's launches); FETCH_SIZE/WRITE_SIZE are reported in KiB by "
                         "rocprofv3; reads corrected x2 as MI355X_MICROARCH.md (HBM section) prescribes for gfx950",
                "workload": workload, "kernels": kernels, "by_phase": phase}, open(out, "w"), indent=1)
     print(json.dumps(phase))

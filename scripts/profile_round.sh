@@ -9,6 +9,11 @@ timeout -k 10 200 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err || exit 
 timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o c2 -- python bench.py --no-cpu-baseline > $O/kt.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o c2 -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/pmc_fetch.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o c2 -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/pmc_write.log 2>&1 || exit 1
+# issue counters of the same command (8 SQ + 1 GRBM: one pass)
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -o c2 -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/pmc_sq.log 2>&1 || exit 1
+# C5: matrix-core counters of the Riccati sweep
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_c5 -o c5 -- python scripts/bench_backward.py --variant riccati --n 64 --m 16 --T 1000 --N 1024 --layout 0 --reps 2 > $O/pmc_c5.log 2>&1 || exit 1
+PYTHONPATH=. timeout -k 10 200 python scripts/bench_c1.py $O/bench_c1.json > $O/bench_c1.log 2>&1 || exit 1
 {
   timeout -k 10 60 python scripts/bench_backward.py --n 2 --m 1 --T 100 --N 1 || exit 1
   for N in 4096 65536; do timeout -k 10 60 python scripts/bench_backward.py --n 4 --m 1 --T 500 --N $N || exit 1; done

@@ -1,0 +1,48 @@
+"""ISA instruction census of one rollout step -> profiles/<tag>_rollout_isa_census.json (runs on the CPU: hipcc -S).
+
+  python scripts/rollout_census.py [out.json]
+
+Compiles csrc/rollout.hip to assembly, takes the driver's cartpole kernel (FAST, time-blocked, straight-line blocks:
+the variant bench.py's workload launches), finds its block loop (8 steps per trip) and counts the instructions by
+category.  bench.py uses `fp64_flops_per_lane_step` for the rollout's compute roofline; the stamp ties the file to the
+sources it was made from."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from trajopt_amd import _lib  # noqa: E402
+
+KERNELS = {"cartpole": "rollout_kernelINS_7SysPhysILi2EEELb1ELb1ELb1ELb1ELb1EEEvNS_11RolloutArgsE",
+           "pendulum": "rollout_kernelINS_7SysPhysILi1EEELb1ELb1ELb1ELb1ELb1EEEvNS_11RolloutArgsE"}
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_rollout_isa_census.json")
+    res = {"stamp": _lib.source_stamp(), "steps_per_trip": 8, "kernels": {},
+           "note": "block loop of the driver's rollout kernel (8 steps per trip, straight-line); counts are "
+                   "instructions per wave; fp64 flops per lane: 2 per fma, 1 per mul / add"}
+    with tempfile.TemporaryDirectory() as d:
+        asm = os.path.join(d, "rollout.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+                               os.path.join(ROOT, "trajopt_amd", "csrc", "rollout.hip"), "-o", asm], stderr=subprocess.DEVNULL)
+        for env, key in KERNELS.items():
+            js = os.path.join(d, env + ".json")
+            subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "isa_census.py"), asm, key, js])
+            loops = json.load(open(js))["loops"]
+            big = max(loops, key=lambda l: l["instructions"])          # the outermost loop = the block loop
+            per_step = {k: v / 8.0 for k, v in big["by_category"].items()}
+            res["kernels"][env] = {"mangled": key, "trip_instructions": big["instructions"],
+                                   "instructions_per_step": big["instructions"] / 8.0,
+                                   "valu_per_step": big["valu"] / 8.0,
+                                   "fp64_flops_per_lane_step": big["fp64_flops_per_lane"] / 8.0,
+                                   "per_step_by_category": per_step}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({k: (v["instructions_per_step"], v["fp64_flops_per_lane_step"]) for k, v in res["kernels"].items()}))
+
+
+if __name__ == "__main__":
+    main()

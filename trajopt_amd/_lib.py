@@ -79,7 +79,7 @@ class ILQROptions(C.Structure):
 class ILQRPlan(C.Structure):
     """include/trajopt_amd.h::trajopt_ilqr_plan_t"""
     _fields_ = [("structured_cost", C.c_int32), ("fused_quad_bwd", C.c_int32), ("staged_line_search", C.c_int32),
-                ("backward_kernel", C.c_int32)]
+                ("backward_kernel", C.c_int32), ("rollout_straight_line", C.c_int32), ("pad_", C.c_int32)]
 
 
 KERNEL_AUTO, KERNEL_WORKGROUP, KERNEL_MFMA16, KERNEL_LANE, KERNEL_MFMA4 = 0, 1, 2, 3, 4
@@ -114,6 +114,21 @@ EXPORTS = (
     "trajopt_ilqr_init_rollout", "trajopt_ilqr_iterate", "trajopt_ilqr_plan", "trajopt_convert_layout",
     "trajopt_profile_begin", "trajopt_profile_end", "trajopt_profile_select",
 )
+
+def source_stamp():
+    """Hash of the kernel sources (csrc/*.hip, *.h, include/*.h): measurements kept under profiles/ carry the stamp
+    of the sources they were taken on, and bench.py only quotes one whose stamp is the current one."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    root = os.path.dirname(_HERE)
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(root, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
 
 _lib = None
 

@@ -25,6 +25,7 @@ int launch_quadratize(const trajopt_env_t* env, int T, int64_t NP, int layout, i
                       const RefView* rv, int out_layout);
 
 bool fused_qb4_supported(const trajopt_env_t* env, int T, int64_t NP);
+bool rollout_straight_line(int n, int m, size_t NP, int nb_alphas);
 int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want);
 int launch_fused_qb4(const trajopt_env_t* env, const trajopt_backward_io_t& io, int reg, int T, int64_t NP, int retry,
                      const trajopt_lambda_schedule_t& sched, const double* xref, const double* uref,
@@ -394,6 +395,10 @@ int trajopt_ilqr_plan(const trajopt_env_t* env, const trajopt_ilqr_options_t* op
     if (opt->argmin_alpha || opt->nb_alphas < 2 || !ws->pending_list || !ws->pending_count) staged = false;
     plan->staged_line_search = staged;
     plan->backward_kernel = plan->fused_quad_bwd ? TRAJOPT_KERNEL_MFMA4 : backward_kernel_family(n, m, T, NP, GL, TRAJOPT_KERNEL_AUTO);
+    // (the fast rollout variant at all: built-in model, plain cost - rollout.hip)
+    const bool fast = env->model != TRAJOPT_ENV_LQR && !env->slew_rate && env->periodic == 0 && !env->cost_times_dt && env->nb_features == 0;
+    plan->rollout_straight_line = fast && !staged && rollout_straight_line(n, m, (size_t)NP, opt->nb_alphas);
+    plan->pad_ = 0;
     return TRAJOPT_OK;
 }
 

@@ -474,6 +474,11 @@ __global__ void env_step_kernel(StepArgs s) {
     }
 }
 
+// The lone-wave form of the driver's rollout (UNR) is taken while every wave has a SIMD to itself.
+bool rollout_straight_line(int n, int m, size_t NP, int nb_alphas) {
+    return (double)NP * nb_alphas <= 64.0 * 1024.0 && n + m <= 7;
+}
+
 struct RolloutLaunch {
     RolloutArgs a;
     bool tb;   // time-blocked candidate planes (the driver's call)
@@ -495,7 +500,7 @@ struct RolloutLaunch {
                 // straight-line blocks while every wave has a SIMD to itself (and the model's registers allow it)
                 // (tried for dx + du >= 6, where the stage's LDS allows one wave per SIMD anyway: 8192 double cartpoles
                 // 1.90 ms against 1.81 rolled)
-                const bool unr = total <= 64 * 1024 && SYS::N + SYS::M <= 7;
+                const bool unr = rollout_straight_line(SYS::N, SYS::M, a.NP, a.nb_alphas - a.alpha_begin);
                 if (tb && unr && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, true, true>), grid, block, 0, st, a);
                 else if (tb && unr) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, true, true>), grid, block, 0, st, a);
                 else if (tb && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, true, false>), grid, block, 0, st, a);
