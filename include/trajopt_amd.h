@@ -184,6 +184,17 @@ int trajopt_riccati_backward_pass_batched(const double* Cxx, const double* cx, c
                                           int64_t nb_problems, int layout, double* V, double* v, double* K,
                                           double* kff, int32_t* status, void* stream);
 
+/* Closed-loop episodes under the sweep's controller: Riccati.forward_pass / .rollout (riccati.py:52-98) with the
+ * absolute law u_t = kff_t + K_t x_t (riccati/objects.py:128-129) on the env's step (dynamics + noise, e.g.
+ * pendulum.py:131-138).  K (m,n,T), kff (m,T): ONE controller in the reference layout, device memory, shared by all
+ * episodes.  x0 (n, N), noise (T, n, N; the caller's draws, NULL = none), state (T+1, n, N), action (T, m, N), xnext
+ * (T, n, N; may be NULL) and cost (T+1, N) are PROBLEM_MINOR over the N episodes.  cost_t is taken on the unclipped
+ * action with u_{t-1} (zero at t = 0) as the reference does; cost_T = env.cost(x_T, 0, 0, w_T). */
+int trajopt_riccati_forward_pass_batched(const trajopt_env_t* env, int nb_steps, int64_t nb_episodes, const double* x0,
+                                         const double* K, const double* kff, const double* noise,
+                                         const double* weighting, double* state, double* action, double* xnext,
+                                         double* cost, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * SURVEY 8f.2 (first "next" row after the iLQR path).  Max-entropy (GPS) backward pass:
  * replaces trajopt.gps.core.backward_pass, /root/reference/trajopt/gps/src/util.cpp:272-374 (called from

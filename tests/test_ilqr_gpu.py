@@ -465,3 +465,48 @@ def test_reset_takes_torch_and_numpy_kff_alike(oracle):
             out.append((s.host("last_return").copy(), s.host("uref").copy()))
         for o in out[1:]:
             assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
+
+
+def test_riccati_forward_pass_and_rollout_equal_the_stepwise_loop():
+    """Riccati.forward_pass / .rollout run as one kernel launch with the noise drawn up front; the reference steps the
+    env (riccati.py:52-98).  Same generator state -> the same episodes as the stepwise loop written out here with
+    env.reset / env.step / env.cost (one device call each)."""
+    from trajopt_amd import envs
+    from trajopt_amd.riccati import Riccati
+    env = envs.make("Pendulum-TO-v0")
+    env.unwrapped.dt = 0.05
+    T, E = 25, 3
+    solver = Riccati(env, nb_steps=T, init_state=env.init())
+    rng = np.random.default_rng(11)
+    solver.ctl.K = 0.5 * rng.standard_normal((1, 2, T))
+    solver.ctl.kff = 0.3 * rng.standard_normal((1, T))
+    w = solver.weighting
+
+    def stepwise(episodes):
+        u_ = env.unwrapped
+        xs, us, xns, cs = np.zeros((2, T, episodes)), np.zeros((1, T, episodes)), np.zeros((2, T, episodes)), np.zeros((T + 1, episodes))
+        for ep in range(episodes):
+            x = env.reset()
+            for t in range(T):
+                u = solver.ctl.kff[:, t] + solver.ctl.K[..., t] @ x
+                us[:, t, ep] = u
+                cs[t, ep] = u_.cost(x, u, us[:, t - 1, ep] if t > 0 else np.zeros(1), w[t])
+                xs[:, t, ep] = x
+                x, _, _, _ = env.step(u)
+                xns[:, t, ep] = x
+            cs[T, ep] = u_.cost(x, np.zeros(1), np.zeros(1), w[T])
+        return xs, us, xns, cs
+    env.seed(5)
+    xs, us, xns, cs = stepwise(1)
+    env.seed(5)
+    state, action, cost = solver.forward_pass(solver.ctl)
+    assert state.shape == (2, T + 1) and action.shape == (1, T) and cost.shape == (T + 1,)
+    assert_close(state[:, :T], xs[..., 0], "state"); assert_close(state[:, 1:], xns[..., 0], "next state")
+    assert_close(action, us[..., 0], "action"); assert_close(cost, cs[:, 0], "cost")
+    env.seed(9)
+    xs, us, xns, cs = stepwise(E)
+    env.seed(9)
+    data = solver.rollout(E)
+    assert_close(data["x"], xs, "x"); assert_close(data["u"], us, "u"); assert_close(data["xn"], xns, "xn")
+    assert_close(data["c"][-1], cs[-1], "final cost")
+    assert_close(data["c"][:-1], np.repeat(cs[:-1, -1:], E, axis=1), "step costs (riccati.py:71: the last episode's row)")

@@ -109,7 +109,7 @@ EXPORTS = (
     "trajopt_gps_quad_expectation_batched", "trajopt_gps_forward_pass_host", "trajopt_gps_augment_cost_host",
     "trajopt_gps_kl_divergence_host", "trajopt_gps_quad_expectation_host",
     "trajopt_bspilqr_backward_supported", "trajopt_bspilqr_backward_pass_batched", "trajopt_bspilqr_backward_pass_host",
-    "trajopt_riccati_backward_pass_host", "trajopt_riccati_backward_pass_batched",
+    "trajopt_riccati_backward_pass_host", "trajopt_riccati_backward_pass_batched", "trajopt_riccati_forward_pass_batched",
     "trajopt_env_step_batched", "trajopt_ilqr_forward_pass_batched", "trajopt_quadratize_batched",
     "trajopt_ilqr_init_rollout", "trajopt_ilqr_iterate", "trajopt_ilqr_plan", "trajopt_convert_layout",
     "trajopt_profile_begin", "trajopt_profile_end", "trajopt_profile_select",

@@ -519,6 +519,83 @@ struct RolloutLaunch {
     }
 };
 
+// Closed-loop episodes under an absolute time-varying law (row A9's forward pass):
+//   Riccati.forward_pass / .rollout   /root/reference/trajopt/riccati/riccati.py:52-98
+//   LinearControl.action              /root/reference/trajopt/riccati/objects.py:128-129   u_t = kff_t + K_t x_t
+//   env.step                          e.g. /root/reference/trajopt/envs/pendulum/pendulum.py:131-138
+// One thread per episode: cost_t = env.cost(x_t, u_t, u_{t-1}, w_t) on the UNCLIPPED action (u_{-1} = 0: the
+// reference reads the still-zero last column through Python's negative index), x_{t+1} = env.dynamics(x_t, u_t) + noise_t
+// (dynamics clips the action itself), cost_T = env.cost(x_T, 0, 0, w_T).  The noise is drawn by the caller (the env's
+// own generator, so that the episode is the one the reference's loop produces) and added here.
+// K (m, n, T) and kff (m, T) are ONE controller in the reference layout, shared by every episode; x0 (n, N), noise
+// (T, n, N), state (T + 1, n, N), action (T, m, N), xnext (T, n, N; may be NULL), cost (T + 1, N) are PROBLEM_MINOR.
+struct EpisodeArgs {
+    trajopt_env_t env;
+    const double *x0, *K, *kff, *noise, *weighting;
+    double *state, *action, *xnext, *cost;
+    size_t NP;
+    int T;
+};
+
+template <class SYS>
+__global__ __launch_bounds__(64) void episode_kernel(EpisodeArgs a) {
+    constexpr int N = SYS::N, M = SYS::M;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x, NP = a.NP;
+    if (p >= NP) return;
+    const trajopt_env_t& e = a.env;
+    const int n = SYS::n(e), m = SYS::m(e), T = a.T;
+    double x[N], u[M], ul[M], xn[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = i < n ? a.x0[(size_t)i * NP + p] : 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) ul[j] = 0.0;
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            double s = 0.0;
+            if (j < m) {
+                s = a.kff[(size_t)m * t + j];
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    if (i < n) s = fma(a.K[(size_t)m * n * t + j + (size_t)m * i], x[i], s);
+            }
+            u[j] = s;
+        }
+        a.cost[(size_t)t * NP + p] = env_cost<N, M>(e, x, u, ul, a.weighting[t], n, m);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i < n) a.state[((size_t)n * t + i) * NP + p] = x[i];
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+            if (j < m) a.action[((size_t)m * t + j) * NP + p] = u[j];
+        SYS::dynamics(e, x, u, xn);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i < n) {
+                x[i] = xn[i] + (a.noise ? a.noise[((size_t)n * t + i) * NP + p] : 0.0);
+                if (a.xnext) a.xnext[((size_t)n * t + i) * NP + p] = x[i];
+            }
+#pragma unroll
+        for (int j = 0; j < M; ++j) ul[j] = u[j];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (i < n) a.state[((size_t)n * T + i) * NP + p] = x[i];
+    double zero[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) zero[j] = 0.0;
+    a.cost[(size_t)T * NP + p] = env_cost<N, M>(e, x, zero, zero, a.weighting[T], n, m);
+}
+
+struct EpisodeLaunch {
+    EpisodeArgs a;
+    hipStream_t st;
+    template <class SYS>
+    void operator()() {
+        hipLaunchKernelGGL((episode_kernel<SYS>), dim3((unsigned)((a.NP + 63) / 64)), dim3(64), 0, st, a);
+    }
+};
+
 struct StepLaunch {
     StepArgs a;
     int layout;
@@ -574,6 +651,21 @@ int trajopt_ilqr_forward_pass_batched(const trajopt_env_t* env, int nb_steps, in
     return launch_rollout(env, nb_steps, nb_problems, layout, x0, K, kff, xref, uref, weighting, alphas_host, nb_alphas,
                           active, state, action, cost, ret, finite, as_stream(stream), layout, 0, nb_alphas, nullptr,
                           nullptr, nullptr);
+}
+
+int trajopt_riccati_forward_pass_batched(const trajopt_env_t* env, int nb_steps, int64_t nb_episodes, const double* x0,
+                                         const double* K, const double* kff, const double* noise,
+                                         const double* weighting, double* state, double* action, double* xnext,
+                                         double* cost, void* stream) {
+    if (!env || !x0 || !K || !kff || !weighting || !state || !action || !cost) return TRAJOPT_ERR_BAD_ARG;
+    if (nb_steps <= 0 || nb_episodes <= 0) return TRAJOPT_ERR_BAD_ARG;
+    EpisodeLaunch L;
+    L.a.env = *env; L.a.x0 = x0; L.a.K = K; L.a.kff = kff; L.a.noise = noise; L.a.weighting = weighting;
+    L.a.state = state; L.a.action = action; L.a.xnext = xnext; L.a.cost = cost;
+    L.a.NP = (size_t)nb_episodes; L.a.T = nb_steps; L.st = as_stream(stream);
+    if (!dispatch_model(*env, L)) return TRAJOPT_ERR_UNSUPPORTED;
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
 }
 
 int trajopt_env_step_batched(const trajopt_env_t* env, const double* x, const double* u, const double* u_last,

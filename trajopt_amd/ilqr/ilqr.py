@@ -62,7 +62,12 @@ class BatchedILQR:
         import torch
         _lib.require_gpu()
         self.env = env
-        u = env.unwrapped
+        u = env.unwrapped if hasattr(env, "unwrapped") else env
+        if not hasattr(u, "struct"):
+            raise _lib.TrajoptError(
+                "BatchedILQR needs an env with a device model (trajopt_amd.envs: %s has no struct()); for an arbitrary "
+                "Python env use the one-problem class iLQR, which differentiates it on the host and runs the backward "
+                "pass on the GPU (trajopt_amd/ilqr/hostenv.py)" % type(u).__name__)
         if apply_env_kwargs:  # ilqr.py:34-36
             u.slew_rate = slew_rate
             if action_penalty is not None:
@@ -345,6 +350,9 @@ class iLQR:
 
     def forward_pass(self, ctl, alpha):
         """-> state (dm_state, T+1), action (dm_act, T), cost (T+1,)   (ilqr.py:89-102)"""
+        if not self._has_device_model():
+            from .hostenv import HostEnvSolver
+            return HostEnvSolver(self).rollout(ctl, alpha)
         b = self._batched()
         L = LAYOUT_PROBLEM_MINOR
         K = to_device(np.asarray(ctl.K, dtype=np.float64)[None], b.gains_layout, b.device)
@@ -365,8 +373,20 @@ class iLQR:
          diverge) = out
         return lc, xvalue, xuvalue, dV, diverge
 
+    def _has_device_model(self):
+        return hasattr(self.env.unwrapped if hasattr(self.env, "unwrapped") else self.env, "struct")
+
     def run(self, nb_iter=25, verbose=False):
-        """ilqr.py:136-237, executed by the batched device driver with N = 1."""
+        """ilqr.py:136-237, executed by the batched device driver with N = 1 - or, for an env without a device model,
+        by the host loop of hostenv.py around the GPU backward pass."""
+        if not self._has_device_model():
+            from .hostenv import HostEnvSolver
+            _lib.require_gpu()
+            trace = HostEnvSolver(self).run(nb_iter)
+            if verbose:
+                for i, r in enumerate(trace[1:]):
+                    print("iter: ", i, " return: ", r)
+            return trace
         b = self._batched()
         trace = b.run(nb_iter=nb_iter)[0]
         h = lambda k: np.ascontiguousarray(b.host(k)[0])

@@ -88,8 +88,8 @@ def quadratize(env, nb_steps, xref, uref, weighting, convention=0):
     import torch
     _lib.require_gpu()
     if not hasattr(env, "struct"):
-        raise NotImplementedError("quadratisation needs a built-in env model (trajopt_amd.envs); arbitrary Python "
-                                  "dynamics would require autograd, which this package does not depend on")
+        raise _lib.TrajoptError("the device quadratisation needs a built-in env model (trajopt_amd.envs); an arbitrary "
+                                "Python env is expanded on the host by iLQR.run (trajopt_amd/ilqr/hostenv.py)")
     e = env.struct()
     n, m, T = e.dm_state, e.dm_act, int(nb_steps)
     dev = torch.device("cuda", torch.cuda.current_device())

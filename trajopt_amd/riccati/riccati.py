@@ -68,39 +68,47 @@ class Riccati:
         self.weighting = make_weighting(self.nb_steps, activation)
         self.cost = AnalyticalQuadraticCost(self.env_cost, self.dm_state, self.dm_act, self.nb_steps + 1)
 
+    def _episodes(self, ctl, nb_episodes, env):
+        """`nb_episodes` closed-loop episodes of `ctl` on the noisy env, integrated by ONE kernel launch
+        (trajopt_riccati_forward_pass_batched): the initial states and the per-step noise are drawn here, with the
+        env's own generator in the order the reference's loops consume it (reset, then one draw per step, episode after
+        episode: riccati.py:66-72,91-95), uploaded once and added on the device.
+        -> state (n, T + 1, N), action (m, T, N), xnext (n, T, N), cost (T + 1, N)"""
+        import torch
+        _lib.require_gpu()
+        u = env.unwrapped
+        N, n, m, T = int(nb_episodes), self.dm_state, self.dm_act, self.nb_steps
+        x0, noise = np.zeros((N, n)), np.zeros((N, T, n))
+        for ep in range(N):
+            x0[ep] = env.reset()
+            noise[ep] = u.np_random.multivariate_normal(np.zeros(n), u.noise(), size=T)   # mean + these = env.step's draws
+        dev = torch.device("cuda", torch.cuda.current_device())
+        f64 = dict(dtype=torch.float64, device=dev)
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), **f64)
+        x0d, nzd = t(x0.T), t(noise.transpose(1, 2, 0))                       # (n, N), (T, n, N)
+        Kd = t(np.asarray(ctl.K, dtype=np.float64).reshape(m, n, T).flatten(order="F"))
+        kd = t(np.asarray(ctl.kff, dtype=np.float64).reshape(m, T).flatten(order="F"))
+        wd = t(np.asarray(self.weighting, dtype=np.float64))
+        st, ac = torch.empty((T + 1, n, N), **f64), torch.empty((T, m, N), **f64)
+        xn, co = torch.empty((T, n, N), **f64), torch.empty((T + 1, N), **f64)
+        e = u.struct()
+        check(lib().trajopt_riccati_forward_pass_batched(
+            C.byref(e), T, C.c_int64(N), _lib.dptr(x0d), _lib.dptr(Kd), _lib.dptr(kd), _lib.dptr(nzd), _lib.dptr(wd),
+            _lib.dptr(st), _lib.dptr(ac), _lib.dptr(xn), _lib.dptr(co), _lib.stream_ptr()))
+        st, ac, xn, co = (a.cpu().numpy() for a in (st, ac, xn, co))
+        u.state = st[T, :, N - 1].copy()                                       # where the last episode left the env
+        return st.transpose(1, 0, 2), ac.transpose(1, 0, 2), xn.transpose(1, 0, 2), co
+
     def rollout(self, nb_episodes, env=None):  # riccati.py:52-83
-        if env is None:
-            env, env_cost = self.env, self.env_cost
-        else:
-            env_cost = env.unwrapped.cost
-        data = {'x': np.zeros((self.dm_state, self.nb_steps, nb_episodes)),
-                'u': np.zeros((self.dm_act, self.nb_steps, nb_episodes)),
-                'xn': np.zeros((self.dm_state, self.nb_steps, nb_episodes)),
-                'c': np.zeros((self.nb_steps + 1, nb_episodes))}
-        for n in range(nb_episodes):
-            x = env.reset()
-            for t in range(self.nb_steps):
-                u = self.ctl.action(x, t)
-                data['u'][..., t, n] = u
-                data['c'][t] = env_cost(x, u, data['u'][..., t - 1, n], self.weighting[t])
-                data['x'][..., t, n] = x
-                x, _, _, _ = env.step(u)
-                data['xn'][..., t, n] = x
-            data['c'][-1, n] = env_cost(x, np.zeros((self.dm_act,)), np.zeros((self.dm_act,)), self.weighting[-1])
-        return data
+        state, action, xnext, cost = self._episodes(self.ctl, nb_episodes, self.env if env is None else env)
+        c = cost.copy()
+        c[:-1] = cost[:-1, -1:]   # riccati.py:71 assigns each step's cost to the whole row: the last episode's stays
+        return {'x': np.ascontiguousarray(state[:, :-1]), 'u': np.ascontiguousarray(action),
+                'xn': np.ascontiguousarray(xnext), 'c': c}
 
     def forward_pass(self, ctl):  # riccati.py:85-98: on the NOISY env (env.reset / env.step)
-        state = np.zeros((self.dm_state, self.nb_steps + 1))
-        action = np.zeros((self.dm_act, self.nb_steps))
-        cost = np.zeros((self.nb_steps + 1,))
-        state[..., 0] = self.env.reset()
-        for t in range(self.nb_steps):
-            action[..., t] = ctl.action(state[..., t], t)
-            cost[..., t] = self.env_cost(state[..., t], action[..., t], action[..., t - 1], self.weighting[t])
-            state[..., t + 1], _, _, _ = self.env.step(action[..., t])
-        cost[..., -1] = self.env_cost(state[..., -1], np.zeros((self.dm_act,)), np.zeros((self.dm_act,)),
-                                      self.weighting[-1])
-        return state, action, cost
+        state, action, _, cost = self._episodes(ctl, 1, self.env)
+        return np.ascontiguousarray(state[..., 0]), np.ascontiguousarray(action[..., 0]), cost[:, 0].copy()
 
     def backward_pass(self):  # riccati.py:100-126
         lc = LinearControl(self.dm_state, self.dm_act, self.nb_steps)
