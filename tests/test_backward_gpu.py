@@ -302,3 +302,27 @@ def test_a_forced_kernel_family_without_the_shape_is_refused():
         with pytest.raises(TrajoptError):
             backward.ilqr_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"], lam, 1, n, m, T,
                                         N, layout, kernel=kernel)
+
+
+@pytest.mark.parametrize("n,m,T,N", [(33, 7, 9, 4), (64, 16, 6, 4)])
+def test_riccati_sweep_does_not_depend_on_the_kernel_for_asymmetric_or_indefinite_inputs(oracle, n, m, T, N):
+    """The tiled matrix-core kernel (16 < dx <= 64) assumes a symmetric Cxx and a positive definite Quu; the reference
+    (riccati.py:100-126, np.linalg.inv) assumes neither.  Problems that break either assumption must come out as the
+    generic kernel / the oracle computes them, the others untouched."""
+    import torch
+    from trajopt_amd import backward, layout as L, synthetic as S
+    stack = S.backward_inputs(n, m, T, N, seed=31, affine=True)
+    rng = np.random.default_rng(8)
+    stack["Cxx"][1][:, :, T // 2] += 0.3 * rng.standard_normal((n, n))   # problem 1: one asymmetric slice
+    stack["Cuu"][2][...] = -stack["Cuu"][2] - 5.0 * np.eye(m)[:, :, None]  # problem 2: Quu indefinite (negative definite) but invertible
+    d = {k: L.to_device(v, 0) for k, v in stack.items()}
+    o = backward.riccati_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"], d["c"], n, m, T, N, 0)
+    torch.cuda.synchronize()
+    assert not o["status"].cpu().numpy().any()
+    for p in range(N):
+        q = S.problem(stack, p)
+        K, kff, V, v = oracle.riccati_backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"],
+                                                    q["c"], n, m, T)
+        assert_close(L.from_device(o["K"], 0)[p], K, "K of problem %d" % p)
+        assert_close(L.from_device(o["V"], 0)[p], V, "V of problem %d" % p)
+        assert_close(L.from_device(o["v"], 0)[p], v, "v of problem %d" % p)

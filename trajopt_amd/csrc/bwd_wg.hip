@@ -17,6 +17,7 @@ struct WgArgs {
     trajopt_lambda_schedule_t sched;
     const double* c;                // VARIANT 1: affine term (n, T)
     int32_t* status;                // VARIANT 1
+    const int32_t* only;            // VARIANT 1, may be NULL: the problems to run (only[p] != 0)
     size_t NP;
     int n, m, T, reg, retry;
 };
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void bwd_wg_kernel(WgArgs a) {
     const int tid = threadIdx.x, BS = blockDim.x;
     const size_t p = blockIdx.x;
     if (VARIANT == 0 && a.io.active && a.io.active[p] == 0) return;
+    if (VARIANT == 1 && a.only && a.only[p] == 0) return;
     const G<MINOR> g{a.NP, p};
     // gains K / kff: bank io.out_bank[p] when the driver keeps several (trajopt_backward_io_t::out_bank)
     const int kmul = (VARIANT == 0 && a.io.out_bank) ? TRAJOPT_GAIN_BANKS : 1, bank = VARIANT == 0 ? gains_bank(a.io.out_bank, p) : 0;
@@ -440,9 +442,11 @@ int launch_backward_wg(const trajopt_backward_io_t& io, int reg, int n, int m, i
 
 int launch_riccati_wg(const double* Cxx, const double* cx, const double* Cuu, const double* cu, const double* Cxu,
                       const double* A, const double* B, const double* c, int n, int m, int T, int64_t NP,
-                      int layout, double* V, double* v, double* K, double* kff, int32_t* status, hipStream_t st) {
+                      int layout, double* V, double* v, double* K, double* kff, int32_t* status, hipStream_t st,
+                      const int32_t* only) {
     if (n > 64 || m > 16) return TRAJOPT_ERR_UNSUPPORTED;
     WgArgs a{};
+    a.only = only;
     a.io.Cxx = Cxx; a.io.cx = cx; a.io.Cuu = Cuu; a.io.cu = cu; a.io.Cxu = Cxu; a.io.A = A; a.io.B = B;
     a.io.V = V; a.io.v = v; a.io.K = K; a.io.kff = kff;
     a.c = c; a.status = status;

@@ -88,7 +88,8 @@ int launch_backward_wg(const trajopt_backward_io_t& io, int reg, int n, int m, i
                        int retry, const trajopt_lambda_schedule_t& sched, hipStream_t st);
 int launch_riccati_wg(const double* Cxx, const double* cx, const double* Cuu, const double* cu, const double* Cxu,
                       const double* A, const double* B, const double* c, int n, int m, int T, int64_t NP,
-                      int layout, double* V, double* v, double* K, double* kff, int32_t* status, hipStream_t st);
+                      int layout, double* V, double* v, double* K, double* kff, int32_t* status, hipStream_t st,
+                      const int32_t* only = nullptr);   // only: run the problems with only[p] != 0
 
 int launch_riccati_mfma64(const double* Cxx, const double* cx, const double* Cuu, const double* cu, const double* Cxu,
                           const double* A, const double* B, const double* c, int n, int m, int T, int64_t NP,

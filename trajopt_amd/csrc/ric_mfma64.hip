@@ -14,10 +14,13 @@
 // F_t is staged in LDS once per step (B operands and, for F', A operands are read from there), P is exchanged
 // through LDS, everything else stays in registers.  The loads of step t-1 are issued at the top of step t.
 //
-// Preconditions (otherwise use the generic kernel, bwd_wg.hip): PROBLEM_MAJOR layout; Cxx symmetric to round-off,
-// as a Hessian is (the block-column trick reads V' as its own transpose); Quu positive definite - a non-positive
-// pivot is reported through status[p] = t + 1 exactly like a singular Quu, whereas np.linalg.inv (riccati.py:118)
-// would also invert an indefinite one.
+// What this kernel assumes beyond riccati.py:100-126 - PROBLEM_MAJOR layout; Cxx symmetric to round-off, as a Hessian
+// is (the block-column trick reads V' as its own transpose); Quu positive definite (LDL' without pivoting, whereas
+// np.linalg.inv at riccati.py:118 also inverts an indefinite matrix) - is CHECKED, per problem: a pre-pass compares
+// every Cxx slice with its transpose (ric_symcheck_kernel) and a non-positive pivot stops the sweep; either way the
+// problem is flagged and the generic kernel (bwd_wg.hip: pivoted LU, no symmetry assumption) then redoes exactly the
+// flagged problems.  The results therefore do not depend on which kernel the dispatcher picks.
+#include <mutex>
 #include "smallmat.h"
 
 namespace trajopt {
@@ -28,8 +31,63 @@ struct Ric64Args {
     const double *Cxx, *cx, *Cuu, *cu, *Cxu, *A, *B, *c;
     double *V, *v, *K, *kff;
     int32_t* status;
+    int32_t* redo;   // [nb_problems]: non-zero = this problem belongs to the generic kernel (set by the symmetry pre-pass or here)
     int n, m, T;
 };
+
+// Pre-pass: redo[p] = 1 when some slice of Cxx is not symmetric to round-off (|C_ij - C_ji| > 1e-13 max|C|).
+// One workgroup per slice - the pass is one extra read of Cxx at HBM speed (C5: 33.6 GB, ~10 % of the sweep); the
+// slice goes through LDS so that both triangles are read along rows.
+struct SymArgs {
+    const double* Cxx;
+    int32_t* redo;
+    int n, T;
+};
+__global__ __launch_bounds__(256) void ric_symcheck_kernel(SymArgs a) {
+    __shared__ double tile[64 * 65];
+    __shared__ double red[4];
+    const int n = a.n, tid = threadIdx.x;
+    const size_t p = blockIdx.x, nn = (size_t)n * n;
+    const double* C = a.Cxx + (p * (size_t)(a.T + 1) + blockIdx.y) * nn;
+    double mx = 0.0;
+    for (int e = tid; e < (int)nn; e += 256) {
+        const double x = C[e];
+        tile[(e / n) * 65 + e % n] = x;
+        mx = fmax(mx, fabs(x));
+    }
+    for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    const double tol = 1e-13 * fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    bool asym = false;
+    for (int e = tid; e < (int)nn; e += 256) {
+        const int i = e % n, j = e / n;
+        const double d = fabs(tile[j * 65 + i] - tile[i * 65 + j]);
+        asym = asym || !(d <= tol);   // NaN counts as asymmetric: the generic kernel decides what it means
+    }
+    if (asym) a.redo[p] = 1;
+}
+
+// Per-device flags of the problems handed to the generic kernel, in a static array of the code object (the batched
+// entry points never allocate): resolved once per device like the staging of the allocation-free entry point.
+constexpr int kRicMaxProblems = 1 << 18;
+static __device__ int32_t ric_redo_flags[kRicMaxProblems];
+static std::mutex g_ric_mutex;
+static int32_t* g_ric_flags[64] = {};
+static int ric_flags(int32_t** out) {
+    int dev = -1;
+    TRAJOPT_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return TRAJOPT_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_ric_mutex);
+    if (!g_ric_flags[dev]) {
+        int32_t* ptr = nullptr;
+        TRAJOPT_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(ric_redo_flags)));
+        if (!ptr) return TRAJOPT_ERR_HIP;
+        g_ric_flags[dev] = ptr;
+    }
+    *out = g_ric_flags[dev];
+    return TRAJOPT_OK;
+}
 
 constexpr int kLdk = 66;   // column stride (doubles) of the LDS images of F and P: conflict-free B-operand reads
 constexpr int kLd16 = 17;  // column stride of the 16-row LDS images (Qux, K, Quu partials, L)
@@ -63,6 +121,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
     const int n = a.n, m = a.m, T = a.T;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const size_t p = blockIdx.x;
+    if (a.redo[p] != 0) return;   // an asymmetric Cxx: the generic kernel's problem (block-uniform)
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
     const double* gA = a.A + p * nn * T;
     const double* gB = a.B + p * nm * T;
@@ -339,7 +398,11 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         }
         if (tid < m) okff[(size_t)m * t + tid] = S.kff[tid];
     }
-    if (tid == 0 && a.status) a.status[p] = bad < 0 ? 0 : bad + 1;
+    // a non-positive pivot: Quu is singular or indefinite - the generic kernel's pivoted LU tells which (riccati.py:118)
+    if (tid == 0) {
+        if (bad >= 0) a.redo[p] = 1;
+        if (a.status) a.status[p] = 0;
+    }
 }
 
 // handled = false when the shape / layout is outside this kernel's range.
@@ -351,14 +414,23 @@ int launch_riccati_mfma64(const double* Cxx, const double* cx, const double* Cuu
     if (n <= 16 || n > 64 || m < 1 || m > 16) return TRAJOPT_OK;
     if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && NP != 1) return TRAJOPT_OK;
     if (NP > 0x7fffffff) return TRAJOPT_OK;
+    if (NP > kRicMaxProblems) return TRAJOPT_OK;   // (more problems than flags: the generic kernel takes them all)
+    int32_t* redo = nullptr;
+    const int rc = ric_flags(&redo);
+    if (rc != TRAJOPT_OK) return rc;
     *handled = true;
-    Ric64Args a{Cxx, cx, Cuu, cu, Cxu, A, B, c, V, v, K, kff, status, n, m, T};
+    TRAJOPT_HIP_CHECK(hipMemsetAsync(redo, 0, (size_t)NP * sizeof(int32_t), st));
+    if (T + 1 > 65535) { *handled = false; return TRAJOPT_OK; }   // (grid rows of the pre-pass)
+    const SymArgs sa{Cxx, redo, n, T};
+    hipLaunchKernelGGL(ric_symcheck_kernel, dim3((unsigned)NP, (unsigned)(T + 1)), dim3(256), 0, st, sa);
+    Ric64Args a{Cxx, cx, Cuu, cu, Cxu, A, B, c, V, v, K, kff, status, redo, n, m, T};
     const size_t lds = sizeof(Ric64Lds);
     TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)ric_mfma64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
     hipLaunchKernelGGL(ric_mfma64_kernel, dim3((unsigned)NP), dim3(256), lds, st, a);
     TRAJOPT_HIP_CHECK(hipGetLastError());
-    return TRAJOPT_OK;
+    // the flagged problems, by the kernel without those assumptions (a workgroup of an unflagged problem leaves at once)
+    return launch_riccati_wg(Cxx, cx, Cuu, cu, Cxu, A, B, c, n, m, T, NP, TRAJOPT_LAYOUT_PROBLEM_MAJOR, V, v, K, kff, status, st, redo);
 }
 
 }  // namespace trajopt
