@@ -73,7 +73,9 @@ typedef struct trajopt_lambda_schedule {
  * Slices the recursion never reaches after a divergence are written as zeros (the reference leaves
  * them uninitialised).  *diverge receives the reference's `_diverge` (time index of the failing step,
  * 0 when none - util.cpp:120,146); *failed (may be NULL) receives the unambiguous flag.
- * Copies to the device, runs the same kernels as the batched entry, copies back, synchronises. */
+ * Copies to the device, runs the same kernels as the batched entry, copies back, synchronises.  The device staging and
+ * its pinned host mirror are kept per device and grown on demand (one copy in, one kernel, one copy out per call);
+ * calls on one device are serialised by the library. */
 int trajopt_ilqr_backward_pass_host(const double* Cxx_host, const double* cx_host, const double* Cuu_host,
                                     const double* cu_host, const double* Cxu_host, const double* A_host,
                                     const double* B_host, double lmbda, int reg, int dm_state, int dm_act,

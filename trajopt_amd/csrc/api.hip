@@ -187,9 +187,41 @@ static size_t backward_host_staging_doubles(int n, int m, int T) {
            + 2;                                                               // lmbda, diverge
 }
 
-// The body shared by trajopt_ilqr_backward_pass_host (staging from hipMalloc) and its allocation-free variant
-// (staging = the library's static device array): copy in, zero the outputs, run the batched kernels, copy out.
-static int backward_host_on_staging(double* staging, hipStream_t st, const double* Cxx, const double* cx,
+// Staging of the *_host convenience entry points: one device buffer and one pinned host mirror per device, grown on
+// demand and kept for the process (a call used to pay hipMalloc + hipFree + 19 pageable copies: 0.29 ms for a T = 100
+// pendulum; now one copy in, one kernel, one copy out).  The mutex is held for the whole call: host-array calls on one
+// device are serialised (the batched entry points are the concurrent interface).
+struct HostStage {
+    double *dev = nullptr, *pin = nullptr;
+    size_t cap = 0;
+};
+static std::mutex g_stage_mutex;
+static HostStage g_stage[64];
+static int host_stage_locked(size_t count, HostStage** out) {   // g_stage_mutex held
+    int dev = -1;
+    TRAJOPT_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return TRAJOPT_ERR_UNSUPPORTED;
+    HostStage& h = g_stage[dev];
+    if (h.cap < count) {
+        if (h.dev) (void)hipFree(h.dev);
+        if (h.pin) (void)hipHostFree(h.pin);
+        h = HostStage{};
+        const size_t cap = count + count / 2 + 1024;
+        TRAJOPT_HIP_CHECK(hipMalloc(&h.dev, cap * sizeof(double)));
+        if (hipHostMalloc(&h.pin, cap * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+            (void)hipFree(h.dev);
+            h = HostStage{};
+            return TRAJOPT_ERR_HIP;
+        }
+        h.cap = cap;
+    }
+    *out = &h;
+    return TRAJOPT_OK;
+}
+
+// The body shared by trajopt_ilqr_backward_pass_host (cached staging, pinned mirror) and its allocation-free variant
+// (staging = the library's static device array, no mirror): copy in, zero the outputs, run the batched kernels, copy out.
+static int backward_host_on_staging(double* staging, double* pinned, hipStream_t st, const double* Cxx, const double* cx,
                                     const double* Cuu, const double* cu, const double* Cxu, const double* A,
                                     const double* B, double lmbda, int reg, int n, int m, int T, double* Qxx,
                                     double* Qux, double* Quu, double* qx, double* qu, double* V, double* v,
@@ -206,8 +238,16 @@ static int backward_host_on_staging(double* staging, hipStream_t st, const doubl
     const size_t total = backward_host_staging_doubles(n, m, T);
     double* d = staging;
     const double* din[7];
+    if (pinned) {   // gather the inputs in the pinned mirror: ONE copy to the device
+        double* h = pinned;
+        for (int i = 0; i < 7; ++i) {
+            memcpy(h, in_host[i], in_counts[i] * sizeof(double));
+            h += in_counts[i];
+        }
+        TRAJOPT_HIP_CHECK(hipMemcpyAsync(staging, pinned, in_total * sizeof(double), hipMemcpyHostToDevice, st));
+    }
     for (int i = 0; i < 7; ++i) {
-        TRAJOPT_HIP_CHECK(hipMemcpyAsync(d, in_host[i], in_counts[i] * sizeof(double), hipMemcpyHostToDevice, st));
+        if (!pinned) TRAJOPT_HIP_CHECK(hipMemcpyAsync(d, in_host[i], in_counts[i] * sizeof(double), hipMemcpyHostToDevice, st));
         din[i] = d;
         d += in_counts[i];
     }
@@ -220,7 +260,12 @@ static int backward_host_on_staging(double* staging, hipStream_t st, const doubl
     }
     double* d_lmbda = d;
     int32_t* d_div = reinterpret_cast<int32_t*>(d + 1);
-    TRAJOPT_HIP_CHECK(hipMemcpyAsync(d_lmbda, &lmbda, sizeof(double), hipMemcpyHostToDevice, st));
+    if (pinned) {   // (the memset above covered it; the value travels through the mirror like everything else)
+        pinned[d_lmbda - staging] = lmbda;
+        TRAJOPT_HIP_CHECK(hipMemcpyAsync(d_lmbda, pinned + (d_lmbda - staging), sizeof(double), hipMemcpyHostToDevice, st));
+    } else {
+        TRAJOPT_HIP_CHECK(hipMemcpyAsync(d_lmbda, &lmbda, sizeof(double), hipMemcpyHostToDevice, st));
+    }
     trajopt_backward_io_t io{};
     io.Cxx = din[0]; io.cx = din[1]; io.Cuu = din[2]; io.cu = din[3]; io.Cxu = din[4]; io.A = din[5]; io.B = din[6];
     io.lmbda = d_lmbda;
@@ -229,11 +274,18 @@ static int backward_host_on_staging(double* staging, hipStream_t st, const doubl
     io.diverge = d_div;
     const int rc = trajopt_ilqr_backward_pass_batched(&io, reg, n, m, T, 1, TRAJOPT_LAYOUT_PROBLEM_MAJOR, 0, nullptr, st);
     if (rc != TRAJOPT_OK) return rc;
-    for (int i = 0; i < 10; ++i)
-        TRAJOPT_HIP_CHECK(hipMemcpyAsync(out_host[i], dout[i], out_counts[i] * sizeof(double), hipMemcpyDeviceToHost, st));
     int32_t div = -1;
-    TRAJOPT_HIP_CHECK(hipMemcpyAsync(&div, d_div, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    TRAJOPT_HIP_CHECK(hipStreamSynchronize(st));
+    if (pinned) {   // outputs | lmbda, diverge: ONE copy back, then scattered to the caller's arrays
+        TRAJOPT_HIP_CHECK(hipMemcpyAsync(pinned + in_total, staging + in_total, (total - in_total) * sizeof(double), hipMemcpyDeviceToHost, st));
+        TRAJOPT_HIP_CHECK(hipStreamSynchronize(st));
+        for (int i = 0; i < 10; ++i) memcpy(out_host[i], pinned + (dout[i] - staging), out_counts[i] * sizeof(double));
+        memcpy(&div, pinned + (d_lmbda - staging) + 1, sizeof(int32_t));
+    } else {
+        for (int i = 0; i < 10; ++i)
+            TRAJOPT_HIP_CHECK(hipMemcpyAsync(out_host[i], dout[i], out_counts[i] * sizeof(double), hipMemcpyDeviceToHost, st));
+        TRAJOPT_HIP_CHECK(hipMemcpyAsync(&div, d_div, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        TRAJOPT_HIP_CHECK(hipStreamSynchronize(st));
+    }
     *diverge = div < 0 ? 0 : div;  // util.cpp:120,146
     if (failed) *failed = div >= 0 ? 1 : 0;
     return TRAJOPT_OK;
@@ -253,10 +305,12 @@ int trajopt_ilqr_backward_pass_host(const double* Cxx, const double* cx, const d
         return TRAJOPT_ERR_BAD_ARG;
     if (n <= 0 || m <= 0 || T <= 0) return TRAJOPT_ERR_BAD_ARG;
     if (trajopt_device_count() < 0) return TRAJOPT_ERR_NO_DEVICE;
-    DevBuf buf;  // one allocation: inputs | outputs | scalars
-    TRAJOPT_HIP_CHECK(buf.alloc(backward_host_staging_doubles(n, m, T)));
-    return backward_host_on_staging(buf.p, nullptr, Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, n, m, T, Qxx, Qux, Quu,
-                                    qx, qu, V, v, dV, K, kff, diverge, failed);
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
+    HostStage* h = nullptr;   // inputs | outputs | scalars
+    const int rc = host_stage_locked(backward_host_staging_doubles(n, m, T), &h);
+    if (rc != TRAJOPT_OK) return rc;
+    return backward_host_on_staging(h->dev, h->pin, nullptr, Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, n, m, T, Qxx, Qux,
+                                    Quu, qx, qu, V, v, dV, K, kff, diverge, failed);
 }
 
 // ---- allocation-free variant of trajopt_ilqr_backward_pass_host ----------------------------------------
@@ -313,8 +367,8 @@ int trajopt_ilqr_backward_pass_host_noalloc(const double* Cxx, const double* cx,
     double* staging = nullptr;
     const int rc = static_staging(&staging);
     if (rc != TRAJOPT_OK) return rc;
-    return backward_host_on_staging(staging, as_stream(stream), Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, n, m, T, Qxx,
-                                    Qux, Quu, qx, qu, V, v, dV, K, kff, diverge, failed);
+    return backward_host_on_staging(staging, nullptr, as_stream(stream), Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, n, m, T,
+                                    Qxx, Qux, Quu, qx, qu, V, v, dV, K, kff, diverge, failed);
 }
 
 int trajopt_riccati_backward_pass_host(const double* Cxx, const double* cx, const double* Cuu, const double* cu,
