@@ -155,6 +155,7 @@ typedef struct trajopt_backward_io {
 #define TRAJOPT_KERNEL_MFMA16 2      /* wave = problem, fp64 matrix cores, dx + du <= 16, du <= 4 (bwd_mfma16.hip)  */
 #define TRAJOPT_KERNEL_LANE 3        /* lane = problem, PROBLEM_MINOR, dx <= 6 (bwd_tpp.hip)                        */
 #define TRAJOPT_KERNEL_MFMA4 4       /* four problems per wave, PROBLEM_MINOR, dx <= 4, du = 1 (bwd_mfma4.hip)      */
+#define TRAJOPT_KERNEL_COLUMNS 5     /* eight lanes per problem, PROBLEM_MINOR, dx = 6, du = 1 (bwd_col8.hip)       */
 
 /* 1 when the batched backward pass accepts io->cost_w for this shape, else 0. */
 int trajopt_backward_supports_structured_cost(int dm_state, int dm_act, int nb_steps, int64_t nb_problems, int layout);

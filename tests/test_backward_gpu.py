@@ -50,7 +50,8 @@ def test_ilqr_backward_matches_oracle(oracle, n, m, T, N, layout, reg):
 
 
 # kernel families (trajopt_backward_io_t::kernel, include/trajopt_amd.h): 1 workgroup-per-problem, 2 MFMA
-# wave-per-problem, 3 lane-per-problem, 4 MFMA four-problems-per-wave (0 = the library's own choice)
+# wave-per-problem, 3 lane-per-problem, 4 MFMA four-problems-per-wave, 5 column-per-lane (eight lanes per problem)
+# (0 = the library's own choice)
 
 
 @pytest.mark.parametrize("kernel,n,m,T,N,layout", [
@@ -61,6 +62,7 @@ def test_ilqr_backward_matches_oracle(oracle, n, m, T, N, layout, reg):
     (3, 6, 1, 50, 70, 1), (3, 4, 2, 30, 66, 1), (3, 2, 1, 30, 5, 1),                            # lane = problem
     (4, 4, 1, 64, 130, 1), (4, 4, 1, 40, 1, 0), (4, 3, 1, 33, 21, 1), (4, 2, 1, 100, 3, 1),    # MFMA, 4 problems / wave
     (4, 4, 1, 500, 37, 1),
+    (5, 6, 1, 50, 70, 1), (5, 6, 1, 33, 7, 1), (5, 6, 1, 500, 37, 1), (5, 6, 1, 21, 1, 0),    # eight lanes per problem
 ])
 @pytest.mark.parametrize("reg", [1, 2])
 def test_every_kernel_family_matches_oracle(oracle, kernel, n, m, T, N, layout, reg):
@@ -79,7 +81,7 @@ def test_every_kernel_family_matches_oracle(oracle, kernel, n, m, T, N, layout, 
         assert res["g_norm"][p] == pytest.approx(g, rel=1e-9)
 
 
-@pytest.mark.parametrize("kernel,n,m", [(1, 6, 2), (2, 6, 2), (3, 4, 1), (4, 4, 1), (4, 3, 1)])
+@pytest.mark.parametrize("kernel,n,m", [(1, 6, 2), (2, 6, 2), (3, 4, 1), (4, 4, 1), (4, 3, 1), (5, 6, 1)])
 def test_asymmetric_cost_hessians_are_taken_as_given(oracle, kernel, n, m):
     """util.cpp uses Cxx as passed (no symmetry assumed); only V is symmetrised (:161)."""
     from trajopt_amd import synthetic as S
@@ -146,6 +148,53 @@ def test_divergence_index_and_partial_outputs(oracle, n, m, layout):
         else:
             assert not failed and res["diverge"][p] == -1
             assert_close(res["K"][p], ref[8], "K")
+
+
+@pytest.mark.parametrize("kernel", [3, 5])
+@pytest.mark.parametrize("reg", [1, 2])
+def test_dx6_families_divergence_partial_outputs_and_retry(oracle, kernel, reg):
+    """The two struct-of-arrays families for dx = 6 (lane = problem, eight lanes per problem; the dispatcher picks by
+    batch size): divergence index, outputs kept above the failing step, untouched below it, and the folded lambda
+    retry loop - with diverging and healthy problems mixed inside one wave."""
+    from trajopt_amd import synthetic as S
+    from trajopt_amd._lib import LambdaSchedule
+    n, m, T, N, at = 6, 1, 19, 13, 7
+    stack = _indefinite(S.backward_inputs(n, m, T, N, seed=21), at, N)
+    res = _run_gpu(stack, 1e-3, reg, n, m, T, N, 1, kernel=kernel)
+    for p in range(N):
+        q = S.problem(stack, p)
+        ref, failed = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], 1e-3, reg, n, m, T)
+        if p % 2 == 1:
+            assert failed and ref[10] == at and res["diverge"][p] == at
+            for k, i in (("V", 5), ("v", 6), ("K", 8), ("kff", 9)):
+                assert_close(res[k][p][..., at + 1:], ref[i][..., at + 1:], k)
+            for k, i in (("Qxx", 0), ("Qux", 1), ("Quu", 2), ("qx", 3), ("qu", 4)):
+                assert_close(res[k][p][..., at:], ref[i][..., at:], k)
+            assert_close(res["dV"][p], ref[7], "dV")
+            assert not np.any(res["K"][p][..., :at + 1]) and not np.any(res["V"][p][..., :at + 1])
+            assert not np.any(res["Qxx"][p][..., :at])
+        else:
+            assert not failed and res["diverge"][p] == -1
+            for k, r in zip(OUT, ref[:10]):
+                assert_close(res[k][p], r, "%s[p=%d]" % (k, p))
+    sched = LambdaSchedule(1e-6, 1e6, 1.6)
+    res = _run_gpu(stack, 1.0, reg, n, m, T, N, 1, retry=True, sched=sched, kernel=kernel)
+    for p in range(N):
+        q = S.problem(stack, p)
+        lam, dlam = 1.0, 1.0
+        while True:
+            ref, failed = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], lam, reg, n, m, T)
+            if not failed:
+                break
+            dlam = max(dlam * 1.6, 1.6)
+            lam = max(lam * dlam, 1e-6)
+            if lam > 1e6:
+                break
+        assert res["lmbda"][p] == pytest.approx(lam, rel=1e-15) and res["dlmbda"][p] == pytest.approx(dlam, rel=1e-15)
+        assert (res["diverge"][p] >= 0) == failed
+        if not failed:
+            for k, r in zip(OUT, ref[:10]):
+                assert_close(res[k][p], r, "%s[p=%d] after retries" % (k, p))
 
 
 @pytest.mark.parametrize("layout", [0, 1])
@@ -234,7 +283,7 @@ def test_riccati_backward_matches_oracle(oracle, n, m, T, N, layout):
         assert_close(L.from_device(o["v"], layout)[p], v, "v")
 
 
-@pytest.mark.parametrize("kernel", [0, 3, 4])
+@pytest.mark.parametrize("kernel", [0, 3, 4, 5])
 @pytest.mark.parametrize("n,m,T,N", [(4, 1, 64, 130), (2, 1, 33, 5), (3, 1, 20, 17), (6, 1, 30, 70), (4, 2, 25, 66)])
 @pytest.mark.parametrize("reg", [1, 2])
 def test_structured_cost_matches_dense_oracle(oracle, kernel, n, m, T, N, reg):
@@ -244,6 +293,8 @@ def test_structured_cost_matches_dense_oracle(oracle, kernel, n, m, T, N, reg):
     from trajopt_amd import backward, layout as L, synthetic as S
     if kernel == 4 and not (m == 1 and n <= 4):
         pytest.skip("the four-problems-per-wave kernel covers dm_state <= 4, dm_act = 1")
+    if kernel == 5 and not (m == 1 and n == 6):
+        pytest.skip("the column-per-lane kernel covers dm_state = 6, dm_act = 1")
     rng = np.random.default_rng(100 * n + m)
     stack = S.backward_inputs(n, m, T, N, seed=900 + n)
     w = np.abs(rng.standard_normal(T + 1)) + 0.1

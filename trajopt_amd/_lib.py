@@ -82,7 +82,7 @@ class ILQRPlan(C.Structure):
                 ("backward_kernel", C.c_int32), ("rollout_straight_line", C.c_int32), ("pad_", C.c_int32)]
 
 
-KERNEL_AUTO, KERNEL_WORKGROUP, KERNEL_MFMA16, KERNEL_LANE, KERNEL_MFMA4 = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_WORKGROUP, KERNEL_MFMA16, KERNEL_LANE, KERNEL_MFMA4, KERNEL_COLUMNS = 0, 1, 2, 3, 4, 5
 
 
 class ILQRWorkspace(C.Structure):

@@ -45,6 +45,11 @@ struct DevBuf {
 // on MI355X, dx = 4: 0.37 vs 0.57 ms at 4096 problems, 0.76 vs 0.60 ms at 8192.
 constexpr int64_t kMfma4MaxProblems = 6144;
 
+// Up to this batch size the column-per-lane kernel (bwd_col8.hip: eight lanes per problem, a step is a third of the
+// dependent instructions but every wave recomputes the shared quantities of its 8 problems) beats lane = problem for
+// dx = 6: 8192 problems are 1024 waves instead of 128.  Beyond it the chip is full either way and the redundancy loses.
+constexpr int64_t kCol8MaxProblems = 24576;
+
 static bool tpp_offsets_fit(int n, int64_t NP) { return (double)n * n * (double)NP * 8.0 + 512.0 < 4294967296.0; }
 
 }  // namespace trajopt
@@ -61,16 +66,19 @@ int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want
     const bool mfma4_ok = minor && m == 1 && n >= 2 && n <= 4 && (double)(T + 2) * n * n * (double)NP * 8.0 < 4294967296.0;
     const bool lane_ok = minor && tpp_offsets_fit(n, NP) &&
                          ((m == 1 && (n == 2 || n == 3 || n == 4 || n == 6)) || (n == 4 && m == 2));
+    const bool col8_ok = minor && col8_shape_ok(n, m, T, NP);
     const bool mfma16_ok = n + m <= 16 && m <= 4 && n >= 1;
     const bool wg_ok = n <= 64 && m <= 16;
     switch (want) {
         case TRAJOPT_KERNEL_AUTO:
             if (mfma4_ok && NP <= kMfma4MaxProblems) return TRAJOPT_KERNEL_MFMA4;
+            if (col8_ok && NP <= kCol8MaxProblems) return TRAJOPT_KERNEL_COLUMNS;
             if (lane_ok) return TRAJOPT_KERNEL_LANE;
             if (mfma16_ok) return TRAJOPT_KERNEL_MFMA16;
             return wg_ok ? TRAJOPT_KERNEL_WORKGROUP : -1;
         case TRAJOPT_KERNEL_MFMA4: return mfma4_ok ? want : -1;
         case TRAJOPT_KERNEL_LANE: return lane_ok ? want : -1;
+        case TRAJOPT_KERNEL_COLUMNS: return col8_ok ? want : -1;
         case TRAJOPT_KERNEL_MFMA16: return mfma16_ok ? want : -1;
         case TRAJOPT_KERNEL_WORKGROUP: return wg_ok ? want : -1;
         default: return -1;
@@ -125,12 +133,13 @@ int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg,
     trajopt_lambda_schedule_t s = sched ? *sched : trajopt_lambda_schedule_t{1e-6, 1e6, 1.6};
     hipStream_t st = as_stream(stream);
     const int fam = backward_kernel_family(n, m, T, NP, layout, io->kernel);
-    if (fam < 0 || (io->cost_w && fam != TRAJOPT_KERNEL_LANE && fam != TRAJOPT_KERNEL_MFMA4)) return TRAJOPT_ERR_UNSUPPORTED;
+    if (fam < 0 || (io->cost_w && fam != TRAJOPT_KERNEL_LANE && fam != TRAJOPT_KERNEL_MFMA4 && fam != TRAJOPT_KERNEL_COLUMNS)) return TRAJOPT_ERR_UNSUPPORTED;
     bool handled = false;
     int rc = TRAJOPT_OK;
     switch (fam) {
         case TRAJOPT_KERNEL_MFMA4: rc = launch_backward_mfma4(*io, reg, n, m, T, NP, retry, s, st, &handled); break;
         case TRAJOPT_KERNEL_LANE: rc = launch_backward_tpp(*io, reg, n, m, T, NP, retry, s, st, &handled); break;
+        case TRAJOPT_KERNEL_COLUMNS: rc = launch_backward_col8(*io, reg, n, m, T, NP, retry, s, st, &handled); break;
         case TRAJOPT_KERNEL_MFMA16: rc = launch_backward_mfma16(*io, reg, n, m, T, NP, layout, retry, s, st, &handled); break;
         default: break;
     }

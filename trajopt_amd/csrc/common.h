@@ -80,6 +80,9 @@ __device__ __forceinline__ int gains_bank(const int32_t* out_bank, size_t p) { r
 // Kernel launchers implemented per translation unit (all return TRAJOPT_* codes).
 int launch_backward_tpp(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int retry,
                         const trajopt_lambda_schedule_t& sched, hipStream_t st, bool* handled);
+bool col8_shape_ok(int n, int m, int T, int64_t NP);
+int launch_backward_col8(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int retry,
+                         const trajopt_lambda_schedule_t& sched, hipStream_t st, bool* handled);
 int launch_backward_mfma4(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int retry,
                           const trajopt_lambda_schedule_t& sched, hipStream_t st, bool* handled);
 int launch_backward_mfma16(const trajopt_backward_io_t& io, int reg, int n, int m, int T, int64_t NP, int layout,
