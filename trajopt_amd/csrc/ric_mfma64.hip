@@ -16,10 +16,11 @@
 //
 // What this kernel assumes beyond riccati.py:100-126 - PROBLEM_MAJOR layout; Cxx symmetric to round-off, as a Hessian
 // is (the block-column trick reads V' as its own transpose); Quu positive definite (LDL' without pivoting, whereas
-// np.linalg.inv at riccati.py:118 also inverts an indefinite matrix) - is CHECKED, per problem: a pre-pass compares
-// every Cxx slice with its transpose (ric_symcheck_kernel) and a non-positive pivot stops the sweep; either way the
-// problem is flagged and the generic kernel (bwd_wg.hip: pivoted LU, no symmetry assumption) then redoes exactly the
-// flagged problems.  The results therefore do not depend on which kernel the dispatcher picks.
+// np.linalg.inv at riccati.py:118 also inverts an indefinite matrix) - is CHECKED, per problem and on the fly: every
+// slice of Cxx is read both ways and compared (|C_ij - C_ji| <= 1e-13 max |C|: 16 more loads a lane and step, no extra
+// pass over the 33.6 GB of C5's Cxx) and a non-positive pivot stops the sweep; either way the problem is flagged and
+// the generic kernel (bwd_wg.hip: pivoted LU, no symmetry assumption) then redoes exactly the flagged problems.  The
+// results therefore do not depend on which kernel the dispatcher picks.
 #include <mutex>
 #include "smallmat.h"
 
@@ -31,42 +32,9 @@ struct Ric64Args {
     const double *Cxx, *cx, *Cuu, *cu, *Cxu, *A, *B, *c;
     double *V, *v, *K, *kff;
     int32_t* status;
-    int32_t* redo;   // [nb_problems]: non-zero = this problem belongs to the generic kernel (set by the symmetry pre-pass or here)
+    int32_t* redo;   // [nb_problems]: non-zero = this problem belongs to the generic kernel (set by the sweep: asymmetric Cxx slice or non-positive pivot)
     int n, m, T;
 };
-
-// Pre-pass: redo[p] = 1 when some slice of Cxx is not symmetric to round-off (|C_ij - C_ji| > 1e-13 max|C|).
-// One workgroup per slice - the pass is one extra read of Cxx at HBM speed (C5: 33.6 GB, ~10 % of the sweep); the
-// slice goes through LDS so that both triangles are read along rows.
-struct SymArgs {
-    const double* Cxx;
-    int32_t* redo;
-    int n, T;
-};
-__global__ __launch_bounds__(256) void ric_symcheck_kernel(SymArgs a) {
-    __shared__ double tile[64 * 65];
-    __shared__ double red[4];
-    const int n = a.n, tid = threadIdx.x;
-    const size_t p = blockIdx.x, nn = (size_t)n * n;
-    const double* C = a.Cxx + (p * (size_t)(a.T + 1) + blockIdx.y) * nn;
-    double mx = 0.0;
-    for (int e = tid; e < (int)nn; e += 256) {
-        const double x = C[e];
-        tile[(e / n) * 65 + e % n] = x;
-        mx = fmax(mx, fabs(x));
-    }
-    for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    const double tol = 1e-13 * fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-    bool asym = false;
-    for (int e = tid; e < (int)nn; e += 256) {
-        const int i = e % n, j = e / n;
-        const double d = fabs(tile[j * 65 + i] - tile[i * 65 + j]);
-        asym = asym || !(d <= tol);   // NaN counts as asymmetric: the generic kernel decides what it means
-    }
-    if (asym) a.redo[p] = 1;
-}
 
 // Per-device flags of the problems handed to the generic kernel, in a static array of the code object (the batched
 // entry points never allocate): resolved once per device like the staging of the allocation-free entry point.
@@ -89,7 +57,31 @@ static int ric_flags(int32_t** out) {
     return TRAJOPT_OK;
 }
 
-constexpr int kLdk = 66;   // column stride (doubles) of the LDS images of F and P: conflict-free B-operand reads
+#ifndef RIC_DIAG
+#define RIC_DIAG 0   // timing experiments only: 1 = per-phase clock ticks of wave 0 written over v[p][0..7][0] (wrong results)
+#endif
+#if RIC_DIAG
+#define RIC_TICK(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tick_[k] += now_ - last_; last_ = now_; }
+#else
+#define RIC_TICK(k)
+#endif
+constexpr int kLdk = 66;   // column stride (doubles) of the LDS images of F and P: conflict-free 16-byte operand reads
+// Position of inner index k inside a column of the F / P images (and of S.w): the matrix-core operand of lane (c, g) for
+// k-step (kt, s) is element k = 16 kt + 4 s + g, so a lane's 16 operands of a tile row are k = g, g + 4, ... - stored
+// next to each other (16 g + k / 4) they are eight 16-byte LDS reads issued ahead of the 16 MFMAs they feed, where one
+// 8-byte read per MFMA, each waited for on the spot, left the matrix pipe idle half of the time.
+__host__ __device__ constexpr int pk(int k) { return (k & 3) * 16 + (k >> 2); }
+typedef double r64_d2 __attribute__((ext_vector_type(2)));
+// the 16 operands of lane (c, g) from column `col` of an image
+__device__ __forceinline__ void ld16(double (&f)[16], const double* img, int col, int g) {
+    const r64_d2* src = reinterpret_cast<const r64_d2*>(img + col * kLdk + 16 * g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const r64_d2 x = src[e];
+        f[2 * e] = x[0];
+        f[2 * e + 1] = x[1];
+    }
+}
 constexpr int kLd16 = 17;  // column stride of the 16-row LDS images (Qux, K, Quu partials, L)
 
 struct Ric64Lds {
@@ -100,7 +92,22 @@ struct Ric64Lds {
     double QuuP[4][16 * kLd16];  // per-wave partial sums of Quu, (row, col) at row + 17 col
     double L[4][16 * kLd16];   // per-wave copy of the unit lower factor, L[i][k] at i * 17 + k
     double w[64], qx[64], qu[16], kff[16];
+    double X[64 * kLdk];       // [col][row]: Cxx_t as it stands in memory, element (row, col) at pk(row) of column col
+    double cmax[4];            // per-wave max |Cxx_t| (symmetry check)
+    int asym;                  // set when a slice of Cxx fails the symmetry check
 };
+
+typedef unsigned r64_v2u __attribute__((ext_vector_type(2)));
+constexpr unsigned kR64NoStore = 0xfffffff8u;  // beyond any per-problem slice (the launcher checks their sizes)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t r64_rsrc(const double* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ double r64_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {   // 0.0 beyond the range (voff)
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void r64_st(double x, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(r64_v2u, x), r, off, 0, 0);
+}
 
 __device__ __forceinline__ double bcast_lane(double x, int lane) {  // lane is wave-uniform
     int lo = __double2loint(x), hi = __double2hiint(x);
@@ -121,7 +128,6 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
     const int n = a.n, m = a.m, T = a.T;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const size_t p = blockIdx.x;
-    if (a.redo[p] != 0) return;   // an asymmetric Cxx: the generic kernel's problem (block-uniform)
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
     const double* gA = a.A + p * nn * T;
     const double* gB = a.B + p * nm * T;
@@ -135,36 +141,53 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
     double* ov = a.v + p * (size_t)n * (T + 1);
     double* oK = a.K + p * nm * T;
     double* okff = a.kff + p * (size_t)m * T;
+    // Outputs go through range-checked descriptors of this problem's slices: a thread with nothing to store passes an
+    // offset beyond the range and the write is dropped, so every store of the time loop is an unconditional instruction
+    // (stores under branches cannot be counted by hipcc's wait-count pass, which then waits for all of them).
+    const __amdgpu_buffer_rsrc_t rV = r64_rsrc(oV, (unsigned)(nn * (size_t)(T + 1) * 8));
+    const __amdgpu_buffer_rsrc_t rv_ = r64_rsrc(ov, (unsigned)((size_t)n * (T + 1) * 8));
+    const __amdgpu_buffer_rsrc_t rK = r64_rsrc(oK, (unsigned)(nm * (size_t)T * 8));
+    const __amdgpu_buffer_rsrc_t rkff = r64_rsrc(okff, (unsigned)((size_t)m * T * 8));
+    // The cost inputs likewise: a padding lane passes the out-of-range offset and the hardware returns 0.0 - no select
+    // on the loaded value (hipcc scheduled those selects right behind the loads, i.e. waited out the HBM latency at the
+    // top of every step instead of where the values are first used, a phase later).
+    const __amdgpu_buffer_rsrc_t rCxx = r64_rsrc(gCxx, (unsigned)(nn * (size_t)(T + 1) * 8));
+    const __amdgpu_buffer_rsrc_t rCxu = r64_rsrc(gCxu, (unsigned)(nm * (size_t)(T + 1) * 8));
+    const __amdgpu_buffer_rsrc_t rCuu = r64_rsrc(gCuu, (unsigned)(mm * (size_t)(T + 1) * 8));
+    const int wu = __builtin_amdgcn_readfirstlane(tid) >> 6;   // the wave, as a scalar
+    const __amdgpu_buffer_rsrc_t rcq = r64_rsrc(wu < 2 ? gcx : gcu, wu < 3 ? (unsigned)((size_t)(wu < 2 ? n : m) * (T + 1) * 8) : 0u);
 
     // ---- staging map of F_t = [A_t B_t c_t]: thread-private slots, fixed for the whole sweep -----------------
     // Slots beyond the matrix re-read element 0 and are parked in a pad word that nothing reads (k = 64 of col 0):
     // no per-slot predicates (20 of them as SGPR pairs made hipcc spill scalars through v_writelane).
     constexpr int kPark = 64;
-    int srcA[16], offA[16], srcB[4], offB[4];
+    int offA[16], offB[4];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const int idx = tid + 256 * s;
-        const bool ok = idx < (int)nn;
-        srcA[s] = ok ? idx : 0;
-        offA[s] = ok ? (idx / n) * kLdk + idx % n : kPark;
+        offA[s] = idx < (int)nn ? (idx / n) * kLdk + pk(idx % n) : kPark;
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int idx = tid + 256 * s;
-        const bool ok = idx < (int)nm;
-        srcB[s] = ok ? idx : 0;
-        offB[s] = ok ? (64 + idx / n) * kLdk + idx % n : kPark;
+        offB[s] = idx < (int)nm ? (64 + idx / n) * kLdk + pk(idx % n) : kPark;
     }
-    const int srcc = tid < n ? tid : 0, offc = tid < n ? 80 * kLdk + tid : kPark;
+    const int offc = tid < n ? 80 * kLdk + pk(tid) : kPark;
+    // Every load of the time loop is  descriptor of the problem's array + loop-invariant lane offset (VGPR) + scalar
+    // offset of the step: no vector address arithmetic inside the loop.  A parked slot reads whatever lies at its
+    // offset (the next slice; zero beyond the array).
+    const __amdgpu_buffer_rsrc_t rA = r64_rsrc(gA, (unsigned)(nn * (size_t)T * 8));
+    const __amdgpu_buffer_rsrc_t rB = r64_rsrc(gB, (unsigned)(nm * (size_t)T * 8));
+    const __amdgpu_buffer_rsrc_t rc_ = r64_rsrc(gc, (unsigned)((size_t)n * T * 8));
+    const unsigned vo_tid = (unsigned)tid * 8u, vo_c = (unsigned)(tid < n ? tid : 0) * 8u;
     double fA[16], fB[4], fc;
     auto fetch_F = [&](int t) {  // global -> registers, unconditional
-        const double* pa = gA + nn * (size_t)t;
-        const double* pb = gB + nm * (size_t)t;
+        const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane(t);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) fA[s] = pa[srcA[s]];
+        for (int s = 0; s < 16; ++s) fA[s] = r64_ld(rA, vo_tid, (tu * (unsigned)nn + 256u * s) * 8u);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) fB[s] = pb[srcB[s]];
-        fc = gc[(size_t)n * t + srcc];
+        for (int s = 0; s < 4; ++s) fB[s] = r64_ld(rB, vo_tid, (tu * (unsigned)nm + 256u * s) * 8u);
+        fc = r64_ld(rc_, vo_c, tu * (unsigned)n * 8u);
     };
     auto stage_F = [&]() {       // registers -> LDS
 #pragma unroll
@@ -176,6 +199,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 
     // zero the padding of the F image once (valid entries are overwritten every step), P needs none
     for (int i = tid; i < 81 * kLdk; i += 256) S.F[i] = 0.0;
+    for (int i = tid; i < 64 * kLdk; i += 256) S.X[i] = 0.0;
     __syncthreads();
     fetch_F(T - 1);
     stage_F();
@@ -183,109 +207,206 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
     // ---- terminal condition (riccati.py:104-105): block column w of V, own segment of v ----------------------
     const int col = 16 * w + c;          // the state index this lane owns as a column
     const bool colok = col < n;
-    d4 Vt[4];
+    // lane offsets of the cost inputs: element (row, col) of this lane's block column read along the contiguous index,
+    // i.e. as C[col][row] (voT) - and, for the symmetry check, as it stands (voS); padding lanes pass the dropped offset
+    unsigned voT[16], voS[16], voXu[4], voUu[4];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int I = 0; I < 4; ++I)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = 16 * kt + g + 4 * r;
-            double x = 0.0;
-            if (colok && row < n) {
-                x = gCxx[nn * (size_t)T + col + (size_t)n * row];  // (symmetric) read along the contiguous index
-                oV[nn * (size_t)T + col + (size_t)n * row] = x;
-            }
-            Vt[kt][r] = x;
+            const int row = 16 * I + g + 4 * r;
+            const bool ok = colok && row < n;
+            voT[4 * I + r] = ok ? (unsigned)(col + n * row) * 8u : kR64NoStore;
+            voS[4 * I + r] = ok ? (unsigned)(row + n * col) * 8u : kR64NoStore;
         }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = g + 4 * r;
+        voXu[r] = (colok && i < m) ? (unsigned)(col + n * i) * 8u : kR64NoStore;
+        voUu[r] = (w == 0 && i < m && c < m) ? (unsigned)(i + m * c) * 8u : kR64NoStore;
+    }
+    const unsigned voRow = lane < n ? (unsigned)lane * 8u : kR64NoStore;
+    unsigned vocq;
+    {
+        const int qc = tid >> 1, el = qc < 64 ? qc : qc - 64, ne = qc < 64 ? n : m;
+        vocq = (tid < 160 && el < ne) ? (unsigned)el * 8u : kR64NoStore;
+    }
+    // Symmetry of a slice of Cxx (the block-column trick reads V' as its own transpose): |C_ij - C_ji| <= 1e-13 max |C|,
+    // checked on the fly - each lane compares the transposed read it uses with the straight read of the same element.
+    // sym_lane: this lane's largest difference (NaN / Inf poison it) and its largest magnitude.
+    auto sym_lane = [&](const d4 (&Qt)[5], const double (&xs)[16], double& dmax, double& cmax) {
+        double dm = 0.0, cm = 0.0, poison = 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const double d = Qt[e >> 2][e & 3] - xs[e];
+            dm = fmax(dm, fabs(d));
+            cm = fmax(cm, fabs(xs[e]));
+            poison = fma(d, 0.0, poison);
+        }
+        dmax = dm + poison;
+        for (int o = 32; o >= 1; o >>= 1) cm = fmax(cm, __shfl_xor(cm, o, 64));
+        cmax = cm;
+    };
+    if (tid == 0) S.asym = 0;
+    d4 Vt[4];
+    {
+        d4 Qt[5];
+        double xs[16], dmax, cmax;
+        const unsigned sT = (unsigned)(nn * (size_t)T * 8);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            Qt[e >> 2][e & 3] = r64_ld(rCxx, voT[e], sT);
+            xs[e] = r64_ld(rCxx, voS[e], sT);
+        }
+        sym_lane(Qt, xs, dmax, cmax);
+        if (lane == 0) S.cmax[w] = cmax;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            Vt[e >> 2][e & 3] = Qt[e >> 2][e & 3];
+            r64_st(Qt[e >> 2][e & 3], rV, voT[e] != kR64NoStore ? voT[e] + sT : kR64NoStore);
+        }
+        __syncthreads();
+        const double tol = 1e-13 * fmax(fmax(S.cmax[0], S.cmax[1]), fmax(S.cmax[2], S.cmax[3]));
+        if (!(dmax <= tol)) S.asym = 1;
+    }
     double vown = colok ? gcx[(size_t)n * T + col] : 0.0;
     if (g == 0 && colok) ov[(size_t)n * T + col] = vown;
     __syncthreads();
+    if (S.asym != 0) {   // block-uniform: the generic kernel takes this problem
+        if (tid == 0) {
+            a.redo[p] = 1;
+            if (a.status) a.status[p] = 0;
+        }
+        return;
+    }
 
     int bad = -1;
+    // nothing of the set-up is in flight when the loop starts: its wait counts then cover the loop's own operations only
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#if RIC_DIAG
+    unsigned long long tick_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = T - 1; t >= 0; --t) {
         // ================= Ph1: prefetch, w = 2 V'c + v', P = V' F ==========================================
         fetch_F(t >= 1 ? t - 1 : 0);
+        const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane(t);
         d4 Q[5];
+        // Cxx_t: wave w fetches columns 16 w .. 16 w + 15, lane = row - whole 512-byte rows, every element once - and
+        // hands them to the block through LDS at the end of this phase; Ph2 takes its tile AND the mirrored elements
+        // (the symmetry check) from there.
+        double xs[16];
 #pragma unroll
-        for (int I = 0; I < 4; ++I)
+        for (int jj = 0; jj < 16; ++jj)
+            xs[jj] = r64_ld(rCxx, (16 * wu + jj) < n ? voRow : kR64NoStore, (tu * (unsigned)nn + (unsigned)(n * (16 * wu + jj))) * 8u);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * I + g + 4 * r;
-                const bool ok = colok && row < n;
-                const double x = gCxx[nn * (size_t)t + (ok ? col + (size_t)n * row : 0)];
-                Q[I][r] = ok ? x : 0.0;
-            }
+        for (int r = 0; r < 4; ++r)   // Qux tile starts from Cxu'  (riccati.py:110): element (i, col) = Cxu[col][i]
+            Q[4][r] = r64_ld(rCxu, voXu[r], tu * (unsigned)nm * 8u);
+        d4 qp;  // this wave's part of Quu; wave 0 starts from Cuu (the others read beyond the range: 0.0)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {  // Qux tile starts from Cxu'  (riccati.py:110): element (i, col) = Cxu[col][i]
-            const int i = g + 4 * r;
-            const bool ok = colok && i < m;
-            const double x = gCxu[nm * (size_t)t + (ok ? col + (size_t)n * i : 0)];
-            Q[4][r] = ok ? x : 0.0;
-        }
-        d4 qp = {0.0, 0.0, 0.0, 0.0};  // this wave's part of Quu; wave 0 starts from Cuu
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = g + 4 * r;
-            const bool ok = w == 0 && i < m && c < m;
-            const double x = gCuu[mm * (size_t)t + (ok ? i + (size_t)m * c : 0)];
-            qp[r] = ok ? x : 0.0;
-        }
-        double cq = 0.0;  // cx / cu element for the q vectors (threads 0..159, two per column)
-        {
-            const int qc = tid >> 1;
-            if (tid < 160) {
-                const bool isx = qc < 64;
-                const bool ok = isx ? qc < n : (qc - 64) < m;
-                const double x = isx ? gcx[(size_t)n * t + (ok ? qc : 0)] : gcu[(size_t)m * t + (ok ? qc - 64 : 0)];
-                cq = ok ? x : 0.0;
-            }
-        }
+        for (int r = 0; r < 4; ++r) qp[r] = r64_ld(rCuu, voUu[r], tu * (unsigned)mm * 8u);
+        // cx / cu element for the q vectors (threads 0..159, two per column; waves 0, 1: cx, wave 2: cu)
+        const double cq = r64_ld(rcq, vocq, tu * (unsigned)(wu < 2 ? n : m) * 8u);
+        double fb0[16], fb1[16];   // operand tiles, one ahead of the MFMAs
+        ld16(fb0, S.F, 80, g);      // the c_t column (every lane the same column)
+        ld16(fb1, S.F, c, g);
         {
             double vc = 0.0;  // (V'c)[col] = sum_k V'[col][k] c[k], k = 16 kt + 4 s + g on this lane
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) vc = fma(Vt[kt][s], S.F[80 * kLdk + 16 * kt + 4 * s + g], vc);
+            for (int e = 0; e < 16; ++e) vc = fma(Vt[e >> 2][e & 3], fb0[e], vc);
             vc = xor_sum16(vc);
-            if (g == 0) S.w[col] = fma(2.0, vc, vown);  // riccati.py:112-116
+            if (g == 0) S.w[pk(col)] = fma(2.0, vc, vown);  // riccati.py:112-116
         }
+        // Two tiles at a time, their MFMAs alternating: a chain of 16 MFMAs on one accumulator leaves the matrix pipe
+        // idle between dependent issues, two independent chains keep it busy.
         d4 Pw4;
+        double fb2[16], fb3[16];
+        ld16(fb0, S.F, 16 + c, g);
+        auto put_P = [&](const d4& acc, int J) {   // rows 16 w + g + 4 r of column 16 J + c: positions 16 g + 4 w + r
+            r64_d2* dst = reinterpret_cast<r64_d2*>(&S.P[(16 * J + c) * kLdk + 16 * g + 4 * w]);
+            dst[0] = r64_d2{acc[0], acc[1]};
+            dst[1] = r64_d2{acc[2], acc[3]};
+        };
+        {
+            ld16(fb2, S.F, 32 + c, g);
+            ld16(fb3, S.F, 48 + c, g);
+            d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int J = 0; J < 5; ++J) {
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[kt][s], S.F[(16 * J + c) * kLdk + 16 * kt + 4 * s + g], acc,
-                                                               0, 0, 0);
-            if (J < 4) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S.P[(16 * J + c) * kLdk + 16 * w + g + 4 * r] = acc[r];
-            } else {
-                Pw4 = acc;
+            for (int e = 0; e < 16; ++e) {
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb1[e], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb0[e], a1, 0, 0, 0);
             }
+            put_P(a0, 0);
+            put_P(a1, 1);
         }
+        {
+            ld16(fb1, S.F, 64 + c, g);
+            d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb2[e], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb3[e], a1, 0, 0, 0);
+            }
+            put_P(a0, 2);
+            put_P(a1, 3);
+        }
+        {
+            // the B block column: two half-chains, added at the end
+            d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb1[e], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[(e + 8) >> 2][(e + 8) & 3], fb1[e + 8], a1, 0, 0, 0);
+            }
+            Pw4 = a0 + a1;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) S.X[(16 * w + jj) * kLdk + pk(lane)] = xs[jj];
+        RIC_TICK(0)
         __syncthreads();
+        RIC_TICK(1)
 
         // ================= Ph2: Q(:, w) = C(:, w) + F' P(:, w), Quu part, q vectors ===========================
+        double dmax_t;
         {
-            d4 Pc[4];
+            double cmax_t;
+            double qi[16], mi[16];
+            ld16(qi, S.X, col, g);             // elements (16 I + g + 4 r, col)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) Pc[kt][s] = S.P[(16 * w + c) * kLdk + 16 * kt + 4 * s + g];
-#pragma unroll
-            for (int I = 0; I < 5; ++I)
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.F[(16 * I + c) * kLdk + 16 * kt + 4 * s + g], Pc[kt][s],
-                                                                    Q[I], 0, 0, 0);
+            for (int e = 0; e < 16; ++e) {     // their mirrors (col, 16 I + g + 4 r)
+                mi[e] = S.X[(16 * (e >> 2) + g + 4 * (e & 3)) * kLdk + pk(col)];
+                Q[e >> 2][e & 3] = qi[e];
+            }
+            sym_lane(Q, mi, dmax_t, cmax_t);
+            if (lane == 0) S.cmax[w] = cmax_t;
         }
+        {
+            double Pc[16];
+            ld16(Pc, S.P, 16 * w + c, g);
+            double fb2[16], fb3[16];
+            ld16(fb0, S.F, c, g);
+            ld16(fb1, S.F, 16 + c, g);
+            ld16(fb2, S.F, 32 + c, g);
+            ld16(fb3, S.F, 48 + c, g);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            qp = __builtin_amdgcn_mfma_f64_16x16x4f64(S.F[(64 + c) * kLdk + 16 * w + 4 * s + g], Pw4[s], qp, 0, 0, 0);
+            for (int e = 0; e < 16; ++e) {   // two independent accumulator chains at a time (see Ph1)
+                Q[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[e], Pc[e], Q[0], 0, 0, 0);
+                Q[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[e], Pc[e], Q[1], 0, 0, 0);
+            }
+            ld16(fb0, S.F, 64 + c, g);
+            double fq[4];   // k = 16 w + 4 s + g of B's column c: position 16 g + 4 w + s
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq) fq[sq] = S.F[(64 + c) * kLdk + 16 * g + 4 * w + sq];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                Q[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb2[e], Pc[e], Q[2], 0, 0, 0);
+                Q[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb3[e], Pc[e], Q[3], 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                Q[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[e], Pc[e], Q[4], 0, 0, 0);
+                if ((e & 3) == 3) qp = __builtin_amdgcn_mfma_f64_16x16x4f64(fq[e >> 2], Pw4[e >> 2], qp, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             S.QuuP[w][(g + 4 * r) + kLd16 * c] = qp[r];
@@ -308,9 +429,15 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
                 else S.qu[qc - 64] = cq + sum;
             }
         }
+        RIC_TICK(2)
         __syncthreads();
+        RIC_TICK(3)
 
         // ================= Ph3: Quu = L D L' (every wave, redundantly), K (wave 0), kff (wave 1) ==============
+        {
+            const double tol = 1e-13 * fmax(fmax(S.cmax[0], S.cmax[1]), fmax(S.cmax[2], S.cmax[3]));
+            if (!(dmax_t <= tol)) S.asym = 1;   // read by everybody behind the next barrier
+        }
         stage_F();  // the F image of this step is dead: bring in step t - 1
         double row[16], invd[16];
         bool ok = true;
@@ -366,9 +493,15 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
                 for (int i = 0; i < 16; ++i) S.kff[i] = -0.5 * y[i];         // riccati.py:121
             }
         }
+        RIC_TICK(4)
         __syncthreads();
+        RIC_TICK(5)
 
         // ================= Ph4: V(:, w) = Qxx(:, w) + K' Qux(w), v = qx + 2 Qux' kff, outputs ================
+        if (S.asym != 0) {   // this step's Cxx is not symmetric (block-uniform): nothing of the step is stored
+            bad = t;
+            break;
+        }
 #pragma unroll
         for (int I = 0; I < 4; ++I)
 #pragma unroll
@@ -389,15 +522,24 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
                 const bool okv = colok && rw < n;
                 const double x = okv ? Q[I][r] : 0.0;  // padding stays exactly zero
                 Vt[I][r] = x;
-                if (okv) oV[nn * (size_t)t + col + (size_t)n * rw] = x;  // V' = V: stored along the contiguous index
+                // V' = V: stored along the contiguous index
+                r64_st(x, rV, okv ? (unsigned)((nn * (size_t)t + col + (size_t)n * rw) * 8) : kR64NoStore);
             }
-        if (g == 0 && colok) ov[(size_t)n * t + col] = vown;
-        for (int idx = tid; idx < (int)nm; idx += 256) {
-            const int i = idx % m, j = idx / m;
-            oK[nm * (size_t)t + idx] = S.K[i + kLd16 * j];
+        r64_st(vown, rv_, (g == 0 && colok) ? (unsigned)(((size_t)n * t + col) * 8) : kR64NoStore);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {   // dx du <= 1024 gains: four per thread
+            const int idx = tid + 256 * s4;
+            const bool okk = idx < (int)nm;
+            const int i = okk ? idx % m : 0, j = okk ? idx / m : 0;
+            r64_st(S.K[i + kLd16 * j], rK, okk ? (unsigned)((nm * (size_t)t + idx) * 8) : kR64NoStore);
         }
-        if (tid < m) okff[(size_t)m * t + tid] = S.kff[tid];
+        r64_st(S.kff[tid < m ? tid : 0], rkff, tid < m ? (unsigned)(((size_t)m * t + tid) * 8) : kR64NoStore);
+        RIC_TICK(6)
     }
+#if RIC_DIAG
+    if (tid == 0)
+        for (int k = 0; k < 7; ++k) ov[k] = (double)tick_[k];
+#endif
     // a non-positive pivot: Quu is singular or indefinite - the generic kernel's pivoted LU tells which (riccati.py:118)
     if (tid == 0) {
         if (bad >= 0) a.redo[p] = 1;
@@ -414,15 +556,13 @@ int launch_riccati_mfma64(const double* Cxx, const double* cx, const double* Cuu
     if (n <= 16 || n > 64 || m < 1 || m > 16) return TRAJOPT_OK;
     if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && NP != 1) return TRAJOPT_OK;
     if (NP > 0x7fffffff) return TRAJOPT_OK;
+    if ((double)n * n * (double)(T + 1) * 8.0 >= 4294967296.0 - 1024.0) return TRAJOPT_OK;   // 32-bit offsets inside a problem's slices
     if (NP > kRicMaxProblems) return TRAJOPT_OK;   // (more problems than flags: the generic kernel takes them all)
     int32_t* redo = nullptr;
     const int rc = ric_flags(&redo);
     if (rc != TRAJOPT_OK) return rc;
     *handled = true;
     TRAJOPT_HIP_CHECK(hipMemsetAsync(redo, 0, (size_t)NP * sizeof(int32_t), st));
-    if (T + 1 > 65535) { *handled = false; return TRAJOPT_OK; }   // (grid rows of the pre-pass)
-    const SymArgs sa{Cxx, redo, n, T};
-    hipLaunchKernelGGL(ric_symcheck_kernel, dim3((unsigned)NP, (unsigned)(T + 1)), dim3(256), 0, st, sa);
     Ric64Args a{Cxx, cx, Cuu, cu, Cxu, A, B, c, V, v, K, kff, status, redo, n, m, T};
     const size_t lds = sizeof(Ric64Lds);
     TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)ric_mfma64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
