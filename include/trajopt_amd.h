@@ -203,7 +203,9 @@ int trajopt_riccati_forward_pass_batched(const trajopt_env_t* env, int nb_steps,
  * replaces trajopt.gps.core.backward_pass, /root/reference/trajopt/gps/src/util.cpp:272-374 (called from
  * gps/mbgps.py:250-260): Q.. = -(C.. + F'V'F)/alpha with the affine dynamics term c, the process noise sigma_dyn
  * (n,n,T), the constant c0 (T+1) and the per-step temperature alpha (T); outputs as the reference's tuple
- * Qxx Qux Quu qx qu q0 V v v0 K kff sigma_ctl.  Shapes with a kernel: trajopt_gps_backward_supported().
+ * Qxx Qux Quu qx qu q0 V v v0 K kff sigma_ctl.  Shapes with a kernel: trajopt_gps_backward_supported() - any
+ * dm_state <= 32, dm_act <= 16 (lane-per-problem kernels for the reference's own small shapes, a wave-per-problem
+ * kernel with run-time dimensions for the rest).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct trajopt_gps_backward_io {
     const double* Cxx; const double* cx; const double* Cuu; const double* cu; const double* Cxu; const double* c0;
@@ -286,7 +288,8 @@ int trajopt_gps_quad_expectation_host(const double* mu_host, const double* sigma
  * covariance channel has b*b entries: p, tau (b*b, .), T, X (b*b, b, .), U, Y (b*b, b*b, .), V, Z (b*b, dm_act, .).
  * Q, q, p are read up to slice nb_steps, everything else up to nb_steps - 1.  dS starts at zero (uninitialised in
  * the reference, :132).  tau_mode: what util.cpp:158's read of the not-yet-assigned tau.col(i) means -
- * 0 = tau.col(i+1) (the evident intent, as :152,:155), 1 = zeros.  Shapes: b in {2, 4}, dm_act in {1, 2}.
+ * 0 = tau.col(i+1) (the evident intent, as :152,:155), 1 = zeros.  Shapes: any b <= 8, dm_act <= 8 (lane-per-problem
+ * kernels for b in {2, 4}, dm_act in {1, 2}; a wave-per-problem kernel with run-time dimensions for the rest).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct trajopt_bsp_backward_io {
     const double* Q; const double* q; const double* R; const double* r; const double* P; const double* p;

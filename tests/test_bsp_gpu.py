@@ -39,9 +39,28 @@ def test_bsp_backward_matches_oracle(oracle, b, m, T, N, reg, tau_mode):
             assert_close(res[k][p], r, "%s[p=%d]" % (k, p))
 
 
-def test_bsp_divergence_index_and_partial_outputs(oracle):
+# shapes without an instantiated lane-per-problem kernel: the wave-per-problem kernel with run-time dimensions
+# (gen_wave.hip; bspilqr/src/util.cpp:83 takes any dimensions)
+@pytest.mark.parametrize("b,m", [(3, 1), (6, 2), (5, 3), (2, 4), (8, 4), (1, 1)])
+@pytest.mark.parametrize("reg", [1, 2])
+@pytest.mark.parametrize("tau_mode", [0, 1])
+def test_bsp_backward_any_dimensions_match_oracle(oracle, b, m, reg, tau_mode):
     from trajopt_amd import synthetic as S
-    b, m, T, N, at = 4, 2, 20, 66, {0: 11, 7: 0, 65: 19}
+    T, N = 12, 5
+    stack = S.bsp_inputs(b, m, T, N, seed=57 + 10 * b + m, coupling=2e-2)
+    res = _run_gpu(stack, 0.5, reg, b, m, T, N, tau_mode)
+    for p in range(N):
+        q = S.problem(stack, p)
+        ref, failed = oracle.bsp_backward_pass(*[q[k] for k in ARGS], 0.5, reg, b, m, T, tau_mode=tau_mode)
+        assert not failed and res["diverge"][p] == -1
+        for k, r in zip(OUT, ref[:6]):
+            assert_close(res[k][p], r, "%s[p=%d]" % (k, p))
+
+
+@pytest.mark.parametrize("b,m", [(4, 2), (6, 3)])
+def test_bsp_divergence_index_and_partial_outputs(oracle, b, m):
+    from trajopt_amd import synthetic as S
+    T, N, at = 20, 66, {0: 11, 7: 0, 65: 19}
     stack = {k: np.array(v) for k, v in S.bsp_inputs(b, m, T, N, seed=3).items()}
     for p, t in at.items():
         stack["R"][p, :, :, t] = -50.0 * np.eye(m)
@@ -71,4 +90,5 @@ def test_bsp_host_entry_point_is_the_reference_signature(oracle):
     q["R"][:, :, 9] = -50.0 * np.eye(m)
     out, flag = core.backward_pass_flag(*[q[k] for k in ARGS], 0.5, 1, b, m, T)
     assert out[6] == 9 and flag
-    assert lib().trajopt_bspilqr_backward_supported(4, 2) == 1 and lib().trajopt_bspilqr_backward_supported(6, 2) == 0
+    assert lib().trajopt_bspilqr_backward_supported(4, 2) == 1 and lib().trajopt_bspilqr_backward_supported(6, 2) == 1
+    assert lib().trajopt_bspilqr_backward_supported(9, 2) == 0 and lib().trajopt_bspilqr_backward_supported(4, 9) == 0

@@ -37,6 +37,28 @@ def test_gps_backward_matches_oracle(oracle, n, m, T, N):
             assert_close(res[k][p], r, "%s[p=%d]" % (k, p))
 
 
+# shapes without an instantiated lane-per-problem kernel: the wave-per-problem kernel with run-time dimensions
+# (gen_wave.hip; gps/src/util.cpp:272 takes any dimensions)
+GENERIC = [(5, 3), (12, 4), (3, 4), (8, 1), (16, 8), (1, 1), (32, 16)]
+
+
+@pytest.mark.parametrize("n,m", GENERIC)
+@pytest.mark.parametrize("T,N", [(25, 9), (6, 3)])
+def test_gps_backward_any_dimensions_match_oracle(oracle, n, m, T, N):
+    from trajopt_amd import synthetic as S
+    stack = S.gps_inputs(n, m, T, N, seed=777 + 10 * n + m)
+    res = _run_gpu(stack, n, m, T, N)
+    gains = _run_gpu(stack, n, m, T, N, full=False)
+    for p in range(N):
+        q = S.problem(stack, p)
+        ref, failed = oracle.gps_backward_pass(*[q[k] for k in ARGS], n, m, T)
+        assert not failed and res["diverge"][p] == -1 and res["status"][p] == 0
+        for k, r in zip(OUT, ref[:12]):
+            assert_close(res[k][p], r, "%s[p=%d]" % (k, p))
+    for k in ("K", "kff", "sigma_ctl", "V", "v", "v0"):
+        assert np.array_equal(res[k], gains[k]), k
+
+
 @pytest.mark.parametrize("n,m", [(4, 1), (4, 2)])
 def test_gains_only_variant_writes_the_same_gains(oracle, n, m):
     from trajopt_amd import synthetic as S
@@ -48,7 +70,7 @@ def test_gains_only_variant_writes_the_same_gains(oracle, n, m):
         assert np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("n,m", [(2, 1), (4, 2)])
+@pytest.mark.parametrize("n,m", [(2, 1), (4, 2), (5, 3), (12, 4)])
 def test_positive_definite_quu_stops_the_sweep(oracle, n, m):
     """util.cpp:333-336: Quu = -(Cuu + B'VB)/alpha positive definite (a concave cost) -> diverge = t, the outputs of
     the steps already done stay, the rest are zero."""
@@ -94,7 +116,8 @@ def test_host_entry_point_is_the_reference_signature(oracle):
 def test_unsupported_shapes_are_refused():
     from trajopt_amd._lib import lib
     assert lib().trajopt_gps_backward_supported(4, 1) == 1
-    assert lib().trajopt_gps_backward_supported(12, 4) == 0
+    assert lib().trajopt_gps_backward_supported(12, 4) == 1     # run-time dimensions: dx <= 32, du <= 16
+    assert lib().trajopt_gps_backward_supported(33, 4) == 0 and lib().trajopt_gps_backward_supported(4, 17) == 0
 
 
 # ---- forward_pass, augment_cost, kl_divergence, quad_expectation (gps/src/util.cpp:83-269) ------------------------

@@ -306,7 +306,8 @@ using namespace trajopt;
 
 extern "C" {
 
-int trajopt_bspilqr_backward_supported(int b, int m) { return ((b == 2 || b == 4) && (m == 1 || m == 2)) ? 1 : 0; }
+static bool bsp_lane_shape(int b, int m) { return (b == 2 || b == 4) && (m == 1 || m == 2); }
+int trajopt_bspilqr_backward_supported(int b, int m) { return (bsp_lane_shape(b, m) || bsp_generic_shape_ok(b, m)) ? 1 : 0; }
 
 int trajopt_bspilqr_backward_pass_batched(const trajopt_bsp_backward_io_t* io, int reg, int tau_mode, int b, int m,
                                           int T, int64_t NP, int layout, void* stream) {
@@ -322,6 +323,7 @@ int trajopt_bspilqr_backward_pass_batched(const trajopt_bsp_backward_io_t* io, i
     a.io = *io; a.NP = (size_t)NP; a.T = T; a.reg = reg; a.tau_mode = tau_mode;
     const dim3 grid((unsigned)((NP + 63) / 64));
     hipStream_t st = as_stream(stream);
+    if (!bsp_lane_shape(b, m)) return launch_bsp_backward_generic(*io, reg, tau_mode, b, m, T, NP, st);   // any other b <= 8, du <= 8
     if (!bsp_dispatch(b, m, LaunchBsp{a, grid, st})) return TRAJOPT_ERR_UNSUPPORTED;
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;

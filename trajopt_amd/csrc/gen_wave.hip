@@ -1,0 +1,396 @@
+// Wave-per-problem fallback kernels with run-time dimensions for the two "next" backward passes:
+//   max-entropy (GPS) backward pass     /root/reference/trajopt/gps/src/util.cpp:272-374     any dx <= 32, du <= 16
+//   belief-space iLQR backward pass     /root/reference/trajopt/bspilqr/src/util.cpp:83-204  any b <= 8, du <= 8
+// The reference's Armadillo code takes any dimensions; the lane-per-problem kernels (gps_tpp.hip, bsp_tpp.hip) are
+// instantiated for the shapes the reference's own examples use and these kernels take the rest - the role bwd_wg.hip
+// plays for the iLQR pass.  One 64-lane workgroup per problem; every matrix of a step lives in LDS (column-major,
+// run-time dimensions), the lanes share the elements of each product, the du x du test / inverse runs on lane 0.
+// Built for coverage, not speed: PROBLEM_MINOR accesses of one problem are strided, nothing is prefetched.
+#include "gps_common.h"
+
+namespace trajopt {
+namespace gw {
+
+constexpr int kW = 64;
+
+struct Acc {   // PROBLEM_MINOR element access of one problem
+    size_t NP, p;
+};
+__device__ __forceinline__ double gl(const double* a, size_t E, int t, size_t e, const Acc& x) {
+    return a[((size_t)t * E + e) * x.NP + x.p];
+}
+__device__ __forceinline__ void g2l(double* dst, const double* a, int E, int t, const Acc& x, int lane) {
+    for (int e = lane; e < E; e += kW) dst[e] = gl(a, (size_t)E, t, (size_t)e, x);
+}
+__device__ __forceinline__ void l2g(double* a, int E, int t, const Acc& x, const double* src, int lane) {
+    if (!a) return;
+    for (int e = lane; e < E; e += kW) a[((size_t)t * E + e) * x.NP + x.p] = src[e];
+}
+// C (r x c) = beta C0 + alpha op(A) op(B), inner dimension k; column-major with leading dimensions lda / ldb of the
+// STORED matrices; C must not alias an operand.
+__device__ __forceinline__ void mm(double* C, int r, int c, int k, const double* A, int lda, bool tA, const double* B,
+                                   int ldb, bool tB, double alpha, const double* C0, double beta, int lane) {
+    for (int e = lane; e < r * c; e += kW) {
+        const int i = e % r, j = e / r;
+        double s = 0.0;
+        for (int kk = 0; kk < k; ++kk) {
+            const double x = tA ? A[kk + lda * i] : A[i + lda * kk];
+            const double y = tB ? B[j + ldb * kk] : B[kk + ldb * j];
+            s = fma(x, y, s);
+        }
+        C[e] = C0 ? fma(beta, C0[e], alpha * s) : alpha * s;
+    }
+}
+__device__ __forceinline__ double wsum(double x) {
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+// One lane: Armadillo's is_sympd() rule for the m x m matrix X (as smallmat.h's sympd_factor): tol = 100 eps ||X||_F,
+// ||X - X'||_inf / ||X||_inf <= tol, chol(X - tol I) exists.  Y: m x m scratch.
+__device__ bool sympd_serial(const double* X, int m, double* Y) {
+    double fro = 0.0;
+    for (int k = 0; k < m * m; ++k) fro = fma(X[k], X[k], fro);
+    const double tol = 100.0 * kEps * sqrt(fro);
+    double na = 0.0, nd = 0.0;
+    for (int i = 0; i < m; ++i) {
+        double ra = 0.0, rd = 0.0;
+        for (int j = 0; j < m; ++j) {
+            ra += fabs(X[i + m * j]);
+            rd += fabs(X[i + m * j] - X[j + m * i]);
+        }
+        if (ra != ra) return false;
+        na = fmax(na, ra);
+        nd = fmax(nd, rd);
+    }
+    if (na != 0.0 && !((nd / na) <= tol)) return false;
+    for (int k = 0; k < m * m; ++k) Y[k] = X[k];
+    for (int i = 0; i < m; ++i) Y[i + m * i] -= tol;
+    for (int j = 0; j < m; ++j) {
+        double d = Y[j + m * j];
+        for (int k = 0; k < j; ++k) d = fma(-Y[j + m * k], Y[j + m * k], d);
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        Y[j + m * j] = d;
+        for (int i = j + 1; i < m; ++i) {
+            double s = Y[i + m * j];
+            for (int k = 0; k < j; ++k) s = fma(-Y[i + m * k], Y[j + m * k], s);
+            Y[i + m * j] = s / d;
+        }
+    }
+    return true;
+}
+
+// One lane: Xi = X^-1 and det X by Gauss-Jordan elimination with partial pivoting (the general inv() of the reference);
+// false when a pivot is exactly zero or not a number.  A: m x m scratch.
+__device__ bool inv_serial(const double* X, int m, double* A, double* Xi, double* det) {
+    for (int k = 0; k < m * m; ++k) {
+        A[k] = X[k];
+        Xi[k] = (k % m == k / m) ? 1.0 : 0.0;
+    }
+    double d = 1.0;
+    for (int k = 0; k < m; ++k) {
+        int piv = k;
+        for (int i = k + 1; i < m; ++i)
+            if (fabs(A[i + m * k]) > fabs(A[piv + m * k])) piv = i;
+        const double pv = A[piv + m * k];
+        if (pv == 0.0 || pv != pv) { *det = 0.0; return false; }
+        if (piv != k) {
+            for (int j = 0; j < m; ++j) {
+                const double x = A[k + m * j]; A[k + m * j] = A[piv + m * j]; A[piv + m * j] = x;
+                const double y = Xi[k + m * j]; Xi[k + m * j] = Xi[piv + m * j]; Xi[piv + m * j] = y;
+            }
+            d = -d;
+        }
+        d *= pv;
+        const double ip = 1.0 / pv;
+        for (int j = 0; j < m; ++j) { A[k + m * j] *= ip; Xi[k + m * j] *= ip; }
+        for (int i = 0; i < m; ++i) {
+            if (i == k) continue;
+            const double f = A[i + m * k];
+            for (int j = 0; j < m; ++j) {
+                A[i + m * j] = fma(-f, A[k + m * j], A[i + m * j]);
+                Xi[i + m * j] = fma(-f, Xi[k + m * j], Xi[i + m * j]);
+            }
+        }
+    }
+    *det = d;
+    return d == d;
+}
+
+}  // namespace gw
+
+// ----------------------------------------------------------------------------------------------------------------
+// GPS backward pass, util.cpp:272-374 (algebra as gps_tpp.hip)
+// ----------------------------------------------------------------------------------------------------------------
+struct GpsGenArgs {
+    trajopt_gps_backward_io_t io;
+    size_t NP;
+    int n, m, T;
+};
+
+__global__ __launch_bounds__(64) void gps_generic_kernel(GpsGenArgs a) {
+    using namespace gw;
+    extern __shared__ __align__(16) double sm[];
+    const int n = a.n, m = a.m, T = a.T, nn = n * n, nm = n * m, mm2 = m * m;
+    const int lane = threadIdx.x;
+    const Acc x{a.NP, (size_t)blockIdx.x};
+    const trajopt_gps_backward_io_t& io = a.io;
+    double* ptr = sm;
+    auto take = [&](int k) { double* r = ptr; ptr += k; return r; };
+    double *V = take(nn), *A = take(nn), *Cx = take(nn), *Sg = take(nn), *W = take(nn), *Qxx = take(nn), *Wn = take(nn);
+    double *B = take(nm), *Cxu = take(nm), *Z = take(nm), *Qxu = take(nm), *K = take(nm), *Qux = take(nm);
+    double *Cuu = take(mm2), *Quu = take(mm2), *Qi = take(mm2), *wk = take(mm2), *sg = take(mm2);
+    double *c = take(n), *cx = take(n), *v = take(n), *Vc = take(n), *qx = take(n), *vn = take(n);
+    double *cu = take(m), *qu = take(m), *kff = take(m), *flag = take(4);
+    g2l(V, io.Cxx, nn, T, x, lane);   // util.cpp:318-320
+    g2l(v, io.cx, n, T, x, lane);
+    double v0 = gl(io.c0, 1, T, 0, x);
+    __syncthreads();
+    l2g(io.V, nn, T, x, V, lane);
+    l2g(io.v, n, T, x, v, lane);
+    if (lane == 0) io.v0[(size_t)T * x.NP + x.p] = v0;
+    int status = 0, where = -1;
+    for (int t = T - 1; t >= 0; --t) {
+        g2l(A, io.A, nn, t, x, lane); g2l(B, io.B, nm, t, x, lane); g2l(c, io.c, n, t, x, lane);
+        g2l(Cx, io.Cxx, nn, t, x, lane); g2l(Cuu, io.Cuu, mm2, t, x, lane); g2l(Cxu, io.Cxu, nm, t, x, lane);
+        g2l(cx, io.cx, n, t, x, lane); g2l(cu, io.cu, m, t, x, lane); g2l(Sg, io.sigma_dyn, nn, t, x, lane);
+        const double c0t = gl(io.c0, 1, t, 0, x), al = gl(io.alpha, 1, t, 0, x), na = -1.0 / al;
+        __syncthreads();
+        mm(W, n, n, n, V, n, false, A, n, false, 1.0, nullptr, 0.0, lane);
+        mm(Z, n, m, n, V, n, false, B, n, false, 1.0, nullptr, 0.0, lane);
+        mm(Vc, n, 1, n, V, n, false, c, n, false, 1.0, nullptr, 0.0, lane);
+        __syncthreads();
+        mm(Qxx, n, n, n, A, n, true, W, n, false, na, Cx, na, lane);     // :324
+        mm(Qxu, n, m, n, A, n, true, Z, n, false, na, Cxu, na, lane);    // :326 (Qux = Qxu')
+        mm(Quu, m, m, n, B, n, true, Z, n, false, na, Cuu, na, lane);    // :325
+        for (int i = lane; i < n + m; i += kW) {                          // :328-329
+            const bool isx = i < n;
+            const double* F = isx ? A + n * i : B + n * (i - n);
+            double s = isx ? cx[i] : cu[i - n];
+            for (int k = 0; k < n; ++k) s = fma(F[k], fma(2.0, Vc[k], v[k]), s);
+            if (isx) qx[i] = na * s; else qu[i - n] = na * s;
+        }
+        double part = 0.0;                                               // :330-331
+        for (int e = lane; e < nn; e += kW) part = fma(V[e % n + n * (e / n)], Sg[e / n + n * (e % n)], part);
+        for (int i = lane; i < n; i += kW) part = fma(c[i], Vc[i] + v[i], part);
+        const double q0 = na * (c0t + v0 + wsum(part));
+        __syncthreads();
+        for (int e = lane; e < nm; e += kW) Qux[(e / n) + m * (e % n)] = Qxu[e];   // (j, i) <- (i, j)
+        l2g(io.Qxx, nn, t, x, Qxx, lane); l2g(io.Quu, mm2, t, x, Quu, lane);
+        l2g(io.qx, n, t, x, qx, lane); l2g(io.qu, m, t, x, qu, lane);
+        if (io.q0 && lane == 0) io.q0[(size_t)t * x.NP + x.p] = q0;
+        if (lane == 0) {   // util.cpp:333-338: a positive definite Quu stops the sweep; inv() of a singular one throws
+            const bool pd = sympd_serial(Quu, m, wk);
+            double det = 0.0;
+            const bool ok = pd ? true : inv_serial(Quu, m, wk, Qi, &det);
+            flag[0] = pd ? 1.0 : 0.0;
+            flag[1] = ok ? 1.0 : 0.0;
+            flag[2] = det;
+        }
+        __syncthreads();
+        l2g(io.Qux, nm, t, x, Qux, lane);
+        if (flag[0] != 0.0) { status = 1; where = t; break; }
+        if (flag[1] == 0.0) { status = 2; where = t; break; }
+        const double det = flag[2];
+        mm(K, m, n, m, Qi, m, false, Qxu, n, true, -1.0, nullptr, 0.0, lane);   // :339
+        for (int j = lane; j < m; j += kW) {                                      // :340
+            double s = 0.0;
+            for (int k = 0; k < m; ++k) s = fma(Qi[j + m * k], qu[k], s);
+            kff[j] = -0.5 * s;
+        }
+        for (int e = lane; e < mm2; e += kW) sg[e] = -0.25 * (Qi[e] + Qi[(e / m) + m * (e % m)]);   // :342-343
+        __syncthreads();
+        mm(Wn, n, n, m, Qxu, n, false, K, m, false, -al, Qxx, -al, lane);          // :348
+        for (int i = lane; i < n; i += kW) {                                       // :351
+            double s = qx[i];
+            for (int k = 0; k < m; ++k) s = fma(2.0 * Qxu[i + n * k], kff[k], s);
+            vn[i] = -al * s;
+        }
+        double qk = 0.0;
+        for (int k = 0; k < m; ++k) qk = fma(qu[k], kff[k], qk);
+        double det2 = det;                                                         // det(-2 Quu)
+        for (int k = 0; k < m; ++k) det2 *= -2.0;
+        v0 = -al * (0.5 * qk + q0 + 0.5 * (m * 1.8378770664093453 - log(det2)));  // :352-353, log(2 pi)
+        __syncthreads();
+        for (int e = lane; e < nn; e += kW) V[e] = 0.5 * (Wn[e] + Wn[(e / n) + n * (e % n)]);   // :349
+        for (int i = lane; i < n; i += kW) v[i] = vn[i];
+        __syncthreads();
+        l2g(io.K, nm, t, x, K, lane); l2g(io.kff, m, t, x, kff, lane); l2g(io.sigma_ctl, mm2, t, x, sg, lane);
+        l2g(io.V, nn, t, x, V, lane); l2g(io.v, n, t, x, v, lane);
+        if (lane == 0) io.v0[(size_t)t * x.NP + x.p] = v0;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        io.diverge[x.p] = where;
+        if (io.status) io.status[x.p] = status;
+    }
+}
+
+bool gps_generic_shape_ok(int n, int m) { return n >= 1 && m >= 1 && n <= 32 && m <= 16; }
+
+int launch_gps_backward_generic(const trajopt_gps_backward_io_t& io, int n, int m, int T, int64_t NP, hipStream_t st) {
+    if (!gps_generic_shape_ok(n, m)) return TRAJOPT_ERR_UNSUPPORTED;
+    GpsGenArgs a;
+    a.io = io; a.NP = (size_t)NP; a.n = n; a.m = m; a.T = T;
+    const size_t lds = sizeof(double) * (size_t)(7 * n * n + 6 * n * m + 5 * m * m + 6 * n + 3 * m + 4);
+    TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)gps_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gps_generic_kernel, dim3((unsigned)NP), dim3(64), lds, st, a);
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Belief-space iLQR backward pass, bspilqr/src/util.cpp:83-204 (algebra and quirks as bsp_tpp.hip / oracle/bsp_oracle.hpp)
+// ----------------------------------------------------------------------------------------------------------------
+struct BspGenArgs {
+    trajopt_bsp_backward_io_t io;
+    size_t NP;
+    int b, m, T, reg, tau_mode;
+};
+
+__global__ __launch_bounds__(64) void bsp_generic_kernel(BspGenArgs a) {
+    using namespace gw;
+    extern __shared__ __align__(16) double sm[];
+    const int b = a.b, m = a.m, T = a.T, bb = b * b, bm = b * m, mm2 = m * m;
+    const int lane = threadIdx.x;
+    const Acc x{a.NP, (size_t)blockIdx.x};
+    const trajopt_bsp_backward_io_t& io = a.io;
+    const double lam = io.lmbda[x.p];
+    double* ptr = sm;
+    auto take = [&](int k) { double* r = ptr; ptr += k; return r; };
+    double *S = take(bb), *F = take(bb), *Q = take(bb), *SF = take(bb), *C = take(bb), *Wn = take(bb);
+    double *G = take(bm), *P = take(bm), *SG = take(bm), *Ex = take(bm), *Er = take(bm), *K = take(bm), *DK = take(bm);
+    double *R = take(mm2), *D = take(mm2), *Dr = take(mm2), *Di = take(mm2), *wk = take(mm2);
+    double *s = take(b), *c = take(b), *sn = take(b), *d = take(m), *kf = take(m), *Dk = take(m);
+    double *tau = take(bb), *e = take(bb), *flag = take(4);
+    g2l(S, io.Q, bb, T, x, lane);   // :142-144
+    g2l(s, io.q, b, T, x, lane);
+    g2l(tau, io.p, bb, T, x, lane);
+    __syncthreads();
+    l2g(io.S, bb, T, x, S, lane);
+    l2g(io.s, b, T, x, s, lane);
+    l2g(io.tau, bb, T, x, tau, lane);
+    double dS0 = 0.0, dS1 = 0.0;
+    int where = -1;
+    for (int t = T - 1; t >= 0; --t) {
+        g2l(F, io.F, bb, t, x, lane); g2l(G, io.G, bm, t, x, lane); g2l(R, io.R, mm2, t, x, lane);
+        g2l(P, io.P, bm, t, x, lane); g2l(Q, io.Q, bb, t, x, lane);
+        __syncthreads();
+        mm(SF, b, b, b, S, b, false, F, b, false, 1.0, nullptr, 0.0, lane);
+        mm(SG, b, m, b, S, b, false, G, b, false, 1.0, nullptr, 0.0, lane);
+        // the linear terms (:152-158): one output per lane, the wide operands (b^2 rows) streamed from global memory
+        for (int o = lane; o < b + m + bb; o += kW) {
+            double acc;
+            if (o < b) {                          // c = q + F's + T'tau + 1/2 X'vec(S)
+                acc = gl(io.q, b, t, o, x);
+                for (int k = 0; k < b; ++k) acc = fma(F[k + b * o], s[k], acc);
+                for (int k = 0; k < bb; ++k)
+                    acc = fma(gl(io.T, (size_t)bb * b, t, k + (size_t)bb * o, x), tau[k],
+                              fma(0.5 * gl(io.X, (size_t)bb * b, t, k + (size_t)bb * o, x), S[k], acc));
+                c[o] = acc;
+            } else if (o < b + m) {               // d = r + G's + V'tau + 1/2 Z'vec(S)
+                const int j = o - b;
+                acc = gl(io.r, m, t, j, x);
+                for (int k = 0; k < b; ++k) acc = fma(G[k + b * j], s[k], acc);
+                for (int k = 0; k < bb; ++k)
+                    acc = fma(gl(io.V, (size_t)bb * m, t, k + (size_t)bb * j, x), tau[k],
+                              fma(0.5 * gl(io.Z, (size_t)bb * m, t, k + (size_t)bb * j, x), S[k], acc));
+                d[j] = acc;
+            } else {                              // e = p + U'tau (tau_mode 0) + 1/2 Y'vec(S)
+                const int j = o - b - m;
+                acc = gl(io.p, bb, t, j, x);
+                for (int k = 0; k < bb; ++k) {
+                    if (a.tau_mode == 0) acc = fma(gl(io.U, (size_t)bb * bb, t, k + (size_t)bb * j, x), tau[k], acc);
+                    acc = fma(0.5 * gl(io.Y, (size_t)bb * bb, t, k + (size_t)bb * j, x), S[k], acc);
+                }
+                e[j] = acc;
+            }
+        }
+        __syncthreads();
+        mm(C, b, b, b, F, b, true, SF, b, false, 1.0, Q, 1.0, lane);     // :148
+        mm(D, m, m, b, G, b, true, SG, b, false, 1.0, R, 1.0, lane);     // :149
+        mm(Ex, b, m, b, F, b, true, SG, b, false, 1.0, P, 1.0, lane);    // :150, E = Ex'
+        __syncthreads();
+        // regularised blocks (:160-168): F'(S + lam I)G = F'SG + lam F'G, G'(S + lam I)G = G'SG + lam G'G
+        if (a.reg == 2) {
+            mm(Er, b, m, b, F, b, true, G, b, false, lam, Ex, 1.0, lane);
+            mm(Dr, m, m, b, G, b, true, G, b, false, lam, D, 1.0, lane);
+        } else {
+            for (int k = lane; k < bm; k += kW) Er[k] = Ex[k];
+            for (int k = lane; k < mm2; k += kW) Dr[k] = D[k] + ((k % m == k / m) ? lam : 0.0);
+        }
+        __syncthreads();
+        if (lane == 0) {   // :170-175
+            const bool pd = sympd_serial(Dr, m, wk);
+            double det = 0.0;
+            const bool ok = pd && inv_serial(Dr, m, wk, Di, &det);
+            flag[0] = pd ? 1.0 : 0.0;
+            flag[1] = ok ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if (flag[0] == 0.0 || flag[1] == 0.0) { where = t; break; }
+        mm(K, m, b, m, Di, m, false, Er, b, true, -1.0, nullptr, 0.0, lane);   // :176, K = -Dinv Ereg, Ereg = Er'
+        for (int j = lane; j < m; j += kW) {                                     // :177
+            double acc = 0.0;
+            for (int k = 0; k < m; ++k) acc = fma(Di[j + m * k], d[k], acc);
+            kf[j] = -acc;
+        }
+        __syncthreads();
+        mm(DK, m, b, m, D, m, false, K, m, false, 1.0, nullptr, 0.0, lane);
+        for (int j = lane; j < m; j += kW) {
+            double acc = 0.0;
+            for (int k = 0; k < m; ++k) acc = fma(D[j + m * k], kf[k], acc);
+            Dk[j] = acc;
+        }
+        __syncthreads();
+        {   // :179 (every lane the same sums)
+            double s0 = 0.0, s1 = 0.0;
+            for (int k = 0; k < m; ++k) { s0 = fma(kf[k], d[k], s0); s1 = fma(kf[k], Dk[k], s1); }
+            dS0 += s0;
+            dS1 += 0.5 * s1;
+        }
+        for (int i = lane; i < b; i += kW) {                                     // :183-184
+            double acc = c[i];
+            for (int k = 0; k < m; ++k) acc = fma(K[k + m * i], Dk[k] + d[k], fma(Ex[i + b * k], kf[k], acc));
+            sn[i] = acc;
+        }
+        for (int q = lane; q < bb; q += kW) {                                    // :186-187
+            const int i = q % b, j = q / b;
+            double acc = C[q];
+            for (int k = 0; k < m; ++k)
+                acc = fma(K[k + m * i], DK[k + m * j] + Ex[j + b * k], fma(Ex[i + b * k], K[k + m * j], acc));
+            Wn[q] = acc;
+        }
+        __syncthreads();
+        for (int q = lane; q < bb; q += kW) {
+            S[q] = 0.5 * (Wn[q] + Wn[(q / b) + b * (q % b)]);                    // :188
+            tau[q] = e[q];                                                       // :181
+        }
+        for (int i = lane; i < b; i += kW) s[i] = sn[i];
+        __syncthreads();
+        l2g(io.K, bm, t, x, K, lane); l2g(io.kff, m, t, x, kf, lane);
+        l2g(io.S, bb, t, x, S, lane); l2g(io.s, b, t, x, s, lane); l2g(io.tau, bb, t, x, tau, lane);
+        __syncthreads();
+    }
+    if (lane == 0) {
+        io.dS[x.p] = dS0;
+        io.dS[x.NP + x.p] = dS1;
+        io.diverge[x.p] = where;
+    }
+}
+
+bool bsp_generic_shape_ok(int b, int m) { return b >= 1 && m >= 1 && b <= 8 && m <= 8; }
+
+int launch_bsp_backward_generic(const trajopt_bsp_backward_io_t& io, int reg, int tau_mode, int b, int m, int T,
+                                int64_t NP, hipStream_t st) {
+    if (!bsp_generic_shape_ok(b, m)) return TRAJOPT_ERR_UNSUPPORTED;
+    BspGenArgs a;
+    a.io = io; a.NP = (size_t)NP; a.b = b; a.m = m; a.T = T; a.reg = reg; a.tau_mode = tau_mode;
+    const size_t lds = sizeof(double) * (size_t)(8 * b * b + 7 * b * m + 5 * m * m + 3 * b + 3 * m + 4);
+    hipLaunchKernelGGL(bsp_generic_kernel, dim3((unsigned)NP), dim3(64), lds, st, a);
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+}  // namespace trajopt

@@ -54,6 +54,13 @@ inline bool gps_shape_supported(int n, int m) {
     return (m == 1 && (n == 2 || n == 3 || n == 4 || n == 6)) || (m == 2 && (n == 2 || n == 4));
 }
 
+// gen_wave.hip: wave-per-problem kernels with run-time dimensions for the shapes without an instantiation
+bool gps_generic_shape_ok(int n, int m);
+int launch_gps_backward_generic(const trajopt_gps_backward_io_t& io, int n, int m, int T, int64_t NP, hipStream_t st);
+bool bsp_generic_shape_ok(int b, int m);
+int launch_bsp_backward_generic(const trajopt_bsp_backward_io_t& io, int reg, int tau_mode, int b, int m, int T,
+                                int64_t NP, hipStream_t st);
+
 // fn.template operator()<N, M>() for a supported shape
 template <class F>
 inline bool gps_dispatch(int n, int m, F&& fn) {

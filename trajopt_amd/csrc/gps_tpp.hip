@@ -253,7 +253,7 @@ using namespace trajopt;
 
 extern "C" {
 
-int trajopt_gps_backward_supported(int n, int m) { return gps_shape_supported(n, m) ? 1 : 0; }
+int trajopt_gps_backward_supported(int n, int m) { return (gps_shape_supported(n, m) || gps_generic_shape_ok(n, m)) ? 1 : 0; }
 
 int trajopt_gps_backward_pass_batched(const trajopt_gps_backward_io_t* io, int n, int m, int T, int64_t NP, int layout,
                                       void* stream) {
@@ -264,9 +264,10 @@ int trajopt_gps_backward_pass_batched(const trajopt_gps_backward_io_t* io, int n
     if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return TRAJOPT_ERR_BAD_ARG;
     if (layout != TRAJOPT_LAYOUT_PROBLEM_MINOR && NP != 1) return TRAJOPT_ERR_UNSUPPORTED;  // (one problem: same memory)
     if (!trajopt_gps_backward_supported(n, m)) return TRAJOPT_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    if (!gps_shape_supported(n, m)) return launch_gps_backward_generic(*io, n, m, T, NP, st);   // any other dx <= 32, du <= 16
     GpsArgs a;
     a.io = *io; a.NP = (size_t)NP; a.T = T;
-    hipStream_t st = as_stream(stream);
     if (m == 1) {
         if (n == 2) return gps_launch<2, 1>(a, st);
         if (n == 3) return gps_launch<3, 1>(a, st);
