@@ -23,6 +23,7 @@ PYTHONPATH=. timeout -k 10 200 python scripts/bench_c1.py $O/bench_c1.json > $O/
 } > $O/backward_all_configs.log 2>&1
 timeout -k 10 200 python bench.py --no-cpu-baseline --instances 65536 --steps 5 --warmup 2 > $O/bench_65536.json 2> $O/bench_65536.err || exit 1
 timeout -k 10 200 python bench.py --no-cpu-baseline --env double_cartpole --instances 8192 --steps 5 --warmup 2 > $O/bench_c3.json 2> $O/bench_c3.err || exit 1
+timeout -k 10 200 python bench.py --no-cpu-baseline --env quadrotor --instances 4096 --steps 5 --warmup 2 > $O/bench_c4.json 2> $O/bench_c4.err || exit 1
 PYTHONPATH=. timeout -k 10 200 python -u scripts/bench_gps.py $O/gps_bench.json > $O/gps_bench.log 2>&1 || exit 1
 PYTHONPATH=. timeout -k 10 200 python -u scripts/bench_bsp.py $O/bsp_bench.json > $O/bsp_bench.log 2>&1 || exit 1
 echo done

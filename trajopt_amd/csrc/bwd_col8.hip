@@ -20,7 +20,7 @@
 // dispatcher (api.hip) goes back to lane = problem.
 //
 // PROBLEM_MINOR layout only (element e of step t for consecutive problems is contiguous: the 8 problems of a wave read
-// 64-byte segments).  Inputs are fetched three steps ahead of the arithmetic, unconditionally and with clamped indices;
+// 64-byte segments).  Inputs are fetched two steps ahead of the arithmetic, unconditionally and with clamped indices;
 // stores go through range-checked buffer descriptors and a lane with nothing to store passes an offset beyond the
 // range (unconditional instructions: see fused_qb4.hip on hipcc's wait-count pass).
 #include "smallmat.h"
@@ -156,21 +156,25 @@ __global__ __launch_bounds__(64) void bwd_col8_kernel(Col8Args a) {
         bool alive = !frozen;
         int sdiv = -1;
         double acc0 = 0.0, acc1 = 0.0, gm = -INFINITY;
-        double V[NN], v[N], AA[NN], Bv[N], Xv[N];   // Xv: Cxu, dense cost only
-        Col8In<N> s0, s1, s2, s3;
+        double V[NN], v[N], Bv[N], Xv[N];   // Xv: Cxu, dense cost only
+        Col8In<N> s0, s1, s2;
         auto put_inputs = [&](const Col8In<N>& s) {
 #pragma unroll
             for (int i = 0; i < N / 2; ++i) wq2[(oA_ + N * jw) / 2 + i] = c8_d2{s.a[2 * i], s.a[2 * i + 1]};
             wq[oB_ + jw] = s.bo;
             if constexpr (!SC) wq[oX_ + jw] = s.cxuo;
         };
-        auto get_inputs = [&](double (&A_)[NN], double (&B_)[N], double (&X_)[N]) {
+        // A of the current step stays in LDS and is read a column at a time where it is used (36 doubles held in
+        // registers across the step cost more in AGPR round trips than the 18 reads); B (and Cxu) are read back whole
+        auto get_col = [&](double (&ac)[N], int i) {
 #pragma unroll
-            for (int e = 0; e < NN / 2; ++e) {
-                const c8_d2 x = xq2[oA_ / 2 + e];
-                A_[2 * e] = x[0];
-                A_[2 * e + 1] = x[1];
+            for (int h = 0; h < N / 2; ++h) {
+                const c8_d2 x = xq2[(oA_ + N * i) / 2 + h];
+                ac[2 * h] = x[0];
+                ac[2 * h + 1] = x[1];
             }
+        };
+        auto get_inputs = [&](double (&B_)[N], double (&X_)[N]) {
 #pragma unroll
             for (int i = 0; i < N / 2; ++i) {
                 const c8_d2 x = xq2[oB_ / 2 + i];
@@ -185,7 +189,6 @@ __global__ __launch_bounds__(64) void bwd_col8_kernel(Col8Args a) {
         };
         fetch(s0, T - 1);
         fetch(s1, T >= 2 ? T - 2 : 0);
-        fetch(s2, T >= 3 ? T - 3 : 0);
         {
             // terminal condition (util.cpp:123-124)
             const __amdgpu_buffer_rsrc_t rcT = c8_rsrc(io.cx + (size_t)T * N * NP + p0, 0xffffffffu);
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(64) void bwd_col8_kernel(Col8Args a) {
             put_inputs(s0);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            get_inputs(AA, Bv, Xv);
+            get_inputs(Bv, Xv);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -229,9 +232,9 @@ __global__ __launch_bounds__(64) void bwd_col8_kernel(Col8Args a) {
             double Z[N], P[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                double z = 0.0, pp = 0.0;
+                double z = V[i] * Bv[0], pp = V[i] * s.a[0];   // (a product, not fma(.., 0.0): no zero to materialise)
 #pragma unroll
-                for (int k = 0; k < N; ++k) {
+                for (int k = 1; k < N; ++k) {
                     z = fma(V[i + N * k], Bv[k], z);
                     pp = fma(V[i + N * k], s.a[k], pp);
                 }
@@ -247,19 +250,21 @@ __global__ __launch_bounds__(64) void bwd_col8_kernel(Col8Args a) {
             double Qux[N], Qxxo[N];                      // util.cpp:130 (all of it), util.cpp:128 (own column)
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                double x = SC ? 0.0 : Xv[i];
-                double y = SC ? s.w * gsel[i] : s.cxxo[i];
+                double ac[N];
+                get_col(ac, i);
+                double x = SC ? ac[0] * Z[0] : fma(ac[0], Z[0], Xv[i]);
+                double y = fma(ac[0], P[0], SC ? s.w * gsel[i] : s.cxxo[i]);
 #pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    x = fma(AA[k + N * i], Z[k], x);
-                    y = fma(AA[k + N * i], P[k], y);
+                for (int k = 1; k < N; ++k) {
+                    x = fma(ac[k], Z[k], x);
+                    y = fma(ac[k], P[k], y);
                 }
                 Qux[i] = x;
                 Qxxo[i] = y;
             }
-            double Quxo = SC ? 0.0 : s.cxuo, qxo = s.cxo;  // own elements of Qux and qx (util.cpp:132)
+            double Quxo = SC ? s.a[0] * Z[0] : fma(s.a[0], Z[0], s.cxuo), qxo = fma(s.a[0], v[0], s.cxo);  // own elements of Qux and qx (util.cpp:132)
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
+            for (int k = 1; k < N; ++k) {
                 Quxo = fma(s.a[k], Z[k], Quxo);
                 qxo = fma(s.a[k], v[k], qxo);
             }
@@ -288,9 +293,10 @@ __global__ __launch_bounds__(64) void bwd_col8_kernel(Col8Args a) {
                 }
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    double ba = 0.0;
+                    double ba = 0.0, ac[N];
+                    get_col(ac, i);
 #pragma unroll
-                    for (int k = 0; k < N; ++k) ba = fma(AA[k + N * i], Bv[k], ba);
+                    for (int k = 0; k < N; ++k) ba = fma(ac[k], Bv[k], ba);
                     Qux_r[i] = fma(lam, ba, Qux[i]);
                 }
                 Quxo_r = fma(lam, bao, Quxo);
@@ -298,6 +304,11 @@ __global__ __launch_bounds__(64) void bwd_col8_kernel(Col8Args a) {
             } else if (a.reg == 1) {
                 Quu_r = Quu + lam;
             }
+            // this step's A, B (Cxu) are dead from here on: the next step's (landed a step ago) go out now, to be read
+            // at the end of the step (B) and in the next one (A)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            put_inputs(nx);
             // PD test (util.cpp:145-148): the same value in the eight lanes of a problem
             const bool bad = !(Quu_r - 100.0 * kEps * fabs(Quu_r) > 0.0);
             sdiv = (alive && bad) ? t : sdiv;
@@ -323,11 +334,10 @@ __global__ __launch_bounds__(64) void bwd_col8_kernel(Col8Args a) {
                 const double g = fabs(kff) / (fabs(s.ur) + 1.0);
                 gm = alive ? nanmax(gm, g) : gm;
             }
-            // exchange: W, v and the next step's A to every lane of the problem
+            // exchange: W and v to every lane of the problem
 #pragma unroll
             for (int i = 0; i < N / 2; ++i) wq2[(N * jw) / 2 + i] = c8_d2{Wo[2 * i], Wo[2 * i + 1]};
             wq[oV_ + jw] = vno;
-            put_inputs(nx);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             double Wf[NN];
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(64) void bwd_col8_kernel(Col8Args a) {
                 Wf[2 * e] = x[0];
                 Wf[2 * e + 1] = x[1];
             }
-            get_inputs(AA, Bv, Xv);
+            get_inputs(Bv, Xv);
 #pragma unroll
             for (int i = 0; i < N / 2; ++i) {
                 const c8_d2 x = xq2[oV_ / 2 + i];
@@ -364,21 +374,19 @@ __global__ __launch_bounds__(64) void bwd_col8_kernel(Col8Args a) {
                 }
         };
 
-        // inputs run three steps ahead of the arithmetic (a step is ~2000 cycles, an HBM round trip under load more)
+        // inputs run two steps ahead of the arithmetic (a step is ~3000 cycles, an HBM round trip under load fewer);
+        // three ahead cost more in register traffic (the sets spill to AGPRs) than the extra slack was worth
         int t = T - 1;
-        auto ahead = [&](Col8In<N>& s) { fetch(s, t >= 3 ? t - 3 : 0); };
+        auto ahead = [&](Col8In<N>& s) { fetch(s, t >= 2 ? t - 2 : 0); };
         while (t >= 0) {
-            ahead(s3);
+            ahead(s2);
             step(s0, s1, t);
             if (--t < 0) break;
             ahead(s0);
             step(s1, s2, t);
             if (--t < 0) break;
             ahead(s1);
-            step(s2, s3, t);
-            if (--t < 0) break;
-            ahead(s2);
-            step(s3, s0, t);
+            step(s2, s0, t);
             --t;
         }
 
