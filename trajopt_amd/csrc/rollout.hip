@@ -136,7 +136,12 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     // back from LDS lives in VGPRs (plentiful here); only the fields a model uses survive as registers.  The LQR
     // env indexes its matrices with run-time dimensions and keeps the kernel-argument copy.
     __shared__ trajopt_env_t s_env;
-    __shared__ TbStage<TB ? N + M : 1> s_stage;
+    // Models with more than 8 rows a step (quadrotor: 16) write their candidates straight into the time-blocked planes,
+    // 8 bytes a lane: the stage would take 85 KB a wave (one wave per CU), and with ~2500 fp64 instructions a step the
+    // stores are a small part of such a rollout - the write-combining of L2 / the memory-side cache has 8 steps' time
+    // to complete a 64-byte cell.
+    constexpr bool kDirect = TB && (N + M > 8);
+    __shared__ TbStage<(TB && !kDirect) ? N + M : 1> s_stage;
     if constexpr (SYS::kStatic) {
         // everything but the LQR matrices: [0, lin_A) and [phys, end) - 64 doubles, one pass of the wave
         constexpr unsigned kHead = offsetof(trajopt_env_t, lin_A) / sizeof(double);
@@ -185,21 +190,31 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     double* st = (!TB && a.state) ? a.state + plane * En1 * NP : nullptr;
     double* ac = (!TB && a.action) ? a.action + plane * Em * NP : nullptr;
     double* co = a.cost ? a.cost + (size_t)ai * (size_t)(T + 1) * NP : nullptr;
-    if constexpr (TB) {
-        s_stage.bx[lane] = plane * tb_plane(n, T + 1, NP) + p * kTB;
-        s_stage.bu[lane] = plane * tb_plane(m, T, NP) + p * kTB;
+    const size_t bx_own = TB ? plane * tb_plane(n, T + 1, NP) + p * kTB : 0, bu_own = TB ? plane * tb_plane(m, T, NP) + p * kTB : 0;
+    if constexpr (TB && !kDirect) {
+        s_stage.bx[lane] = bx_own;
+        s_stage.bu[lane] = bu_own;
     }
     // TB: element i of state slice s / element j of action slice t goes to the stage.  Both blocks b = t / 8 are
     // written out together after the step with t % 8 == 7 - BEFORE that step's new state, slice 8 b + 8, which is slot
     // 0 of the next block, is put - and whatever the last, partial blocks hold after the last step.
-    auto put_x = [&](int s, int i, double v) { if (ROLL_DIAG >= 2) return; s_stage.v[(i * 64 + lane) * kStagePad + (s & (kTB - 1))] = v; };
-    auto put_u = [&](int t, int j, double v) { if (ROLL_DIAG >= 2) return; s_stage.v[((n + j) * 64 + lane) * kStagePad + (t & (kTB - 1))] = v; };
+    auto put_x = [&](int s, int i, double v) {
+        if (ROLL_DIAG >= 2) return;
+        if constexpr (kDirect) a.state[bx_own + ((size_t)(s / kTB) * n + i) * NP * kTB + (s & (kTB - 1))] = v;
+        else s_stage.v[(i * 64 + lane) * kStagePad + (s & (kTB - 1))] = v;
+    };
+    auto put_u = [&](int t, int j, double v) {
+        if (ROLL_DIAG >= 2) return;
+        if constexpr (kDirect) a.action[bu_own + ((size_t)(t / kTB) * m + j) * NP * kTB + (t & (kTB - 1))] = v;
+        else s_stage.v[((n + j) * 64 + lane) * kStagePad + (t & (kTB - 1))] = v;
+    };
     auto flush_block = [&](int b) {
-        if (ROLL_DIAG >= 1) return;
+        if (ROLL_DIAG >= 1 || kDirect) return;
         tb_flush(s_stage, s_stage.bx, a.state, 0, n, b, NP, lane);
         tb_flush(s_stage, s_stage.bu, a.action, n, m, b, NP, lane);
     };
     auto flush_tail = [&]() {   // slices 8 (T / 8) .. T of the states, .. T - 1 of the actions
+        if (kDirect) return;
         tb_flush(s_stage, s_stage.bx, a.state, 0, n, T / kTB, NP, lane);
         if (T % kTB != 0) tb_flush(s_stage, s_stage.bu, a.action, n, m, T / kTB, NP, lane);
     };
@@ -240,14 +255,17 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                    *pK = reinterpret_cast<const char*>(a.K), *pkf = reinterpret_cast<const char*>(a.kff),
                    *pw = reinterpret_cast<const char*>(a.weighting);
         auto ld = [](const char* b, unsigned o) { return *reinterpret_cast<const double*>(b + o); };
+        // PROBLEM_MAJOR gains: the elements of a step are consecutive - ONE lane offset and the element in the
+        // instruction's immediate, instead of a register per element (48 for the quadrotor's K)
+        auto ldi = [](const char* b, unsigned o, unsigned imm) { return *reinterpret_cast<const double*>(b + (size_t)o + imm); };
         int tl = 0;  // the slice the pointers address
         auto load = [&](In& s) {
 #pragma unroll
             for (int i = 0; i < N; ++i) s.xr[i] = ld(pxr, ox[i]);
 #pragma unroll
-            for (int j = 0; j < M; ++j) { s.ur[j] = ld(pur, ou[j]); s.kf[j] = ld(pkf, okf[j]); }
+            for (int j = 0; j < M; ++j) { s.ur[j] = ld(pur, ou[j]); s.kf[j] = KMINOR ? ld(pkf, okf[j]) : ldi(pkf, okf[0], 8u * j); }
 #pragma unroll
-            for (int k = 0; k < M * N; ++k) s.K[k] = ld(pK, oK[k]);
+            for (int k = 0; k < M * N; ++k) s.K[k] = KMINOR ? ld(pK, oK[k]) : ldi(pK, oK[0], 8u * k);
             s.w = ld(pw, 0u);
             if (tl + 1 < T) { pxr += sx; pur += su; pK += sK; pkf += skf; pw += 8; ++tl; }
         };
@@ -270,6 +288,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         // (kAhead2: for the lone-wave forms.  Where several waves share a SIMD they hide that wait for each other, and
         // the plain one-step-ahead prefetch into the other register set needs fewer registers - an occupancy step for dx = 6.)
         constexpr bool kAhead2 = !TB || UNR;
+        // (kOne: models with more than 8 rows a step - two register sets of their inputs (quadrotor: 68 doubles each)
+        // do not fit next to the dynamics; ONE set, refilled in place with the next step's inputs as soon as the control
+        // law has consumed it - they arrive while the dynamics integrate.)
+        constexpr bool kOne = kDirect && !kAhead2;
         auto step = [&](In& s, auto put_next_c) {
             constexpr bool put_next = decltype(put_next_c)::value;
             double u[M];  // u = clip(uref + alpha kff + K (x - xref))    objects.py:137-139, ilqr.py:97
@@ -281,7 +303,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 u[j] = clip_g(fma(alpha, s.kf[j], s.ur[j]) + kx, e.umax[j]);
             }
             total += env_cost_plain<N, M>(e, x, u, s.w);  // ilqr.py:98 passes u_last = u_t
-            if constexpr (kAhead2) load(s);
+            if constexpr (kAhead2 || kOne) load(s);
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 if constexpr (TB) put_u(t, j, u[j]);
@@ -312,10 +334,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 if constexpr (UNR) {
 #pragma unroll
                     for (int k = 0; k < kTB / 2; ++k) {
-                        if constexpr (!kAhead2) load(sb);
+                        if constexpr (!kAhead2 && !kOne) load(sb);
                         step(sa, std::true_type{});
                         ++t;
-                        if constexpr (!kAhead2) load(sa);
+                        if constexpr (!kAhead2 && !kOne) load(sa);
                         if (k + 1 < kTB / 2) step(sb, std::true_type{});
                         else step(sb, std::false_type{});
                         ++t;
@@ -323,18 +345,18 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 } else {
 #pragma unroll 1
                     for (int k = 0; k < kTB / 2 - 1; ++k) {
-                        if constexpr (!kAhead2) load(sb);
+                        if constexpr (!kAhead2 && !kOne) load(sb);
                         step(sa, std::true_type{});
                         ++t;
-                        if constexpr (!kAhead2) load(sa);
-                        step(sb, std::true_type{});
+                        if constexpr (!kAhead2 && !kOne) load(sa);
+                        step(kOne ? sa : sb, std::true_type{});
                         ++t;
                     }
-                    if constexpr (!kAhead2) load(sb);
+                    if constexpr (!kAhead2 && !kOne) load(sb);
                     step(sa, std::true_type{});
                     ++t;
-                    if constexpr (!kAhead2) load(sa);
-                    step(sb, std::false_type{});
+                    if constexpr (!kAhead2 && !kOne) load(sa);
+                    step(kOne ? sa : sb, std::false_type{});
                     ++t;
                 }
                 flush_block(b);
@@ -342,20 +364,20 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 for (int i = 0; i < N; ++i) put_x(t, i, x[i]);   // slice 8 b + 8 = slot 0 of the next block
             }
             while (t < T) {   // the last, partial block: fewer than 8 steps
-                if constexpr (!kAhead2) load(sb);
+                if constexpr (!kAhead2 && !kOne) load(sb);
                 step(sa, std::true_type{});
                 if (++t >= T) break;
-                if constexpr (!kAhead2) load(sa);
-                step(sb, std::true_type{});
+                if constexpr (!kAhead2 && !kOne) load(sa);
+                step(kOne ? sa : sb, std::true_type{});
                 ++t;
             }
             flush_tail();
         } else {
             while (t < T) {
-                if constexpr (!kAhead2) load(sb);
+                if constexpr (!kAhead2 && !kOne) load(sb);
                 step(sa, std::true_type{});
                 if (++t >= T) break;
-                if constexpr (!kAhead2) load(sa);
+                if constexpr (!kAhead2 && !kOne) load(sa);
                 step(sb, std::true_type{});
                 ++t;
             }
