@@ -63,6 +63,7 @@ def test_ilqr_backward_matches_oracle(oracle, n, m, T, N, layout, reg):
     (4, 4, 1, 64, 130, 1), (4, 4, 1, 40, 1, 0), (4, 3, 1, 33, 21, 1), (4, 2, 1, 100, 3, 1),    # MFMA, 4 problems / wave
     (4, 4, 1, 500, 37, 1),
     (5, 6, 1, 50, 70, 1), (5, 6, 1, 33, 7, 1), (5, 6, 1, 500, 37, 1), (5, 6, 1, 21, 1, 0),    # eight lanes per problem
+    (5, 6, 1, 1, 3, 1), (5, 6, 1, 2, 9, 1), (5, 6, 1, 3, 8, 1), (3, 6, 1, 1, 3, 1),
 ])
 @pytest.mark.parametrize("reg", [1, 2])
 def test_every_kernel_family_matches_oracle(oracle, kernel, n, m, T, N, layout, reg):
