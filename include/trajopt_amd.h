@@ -244,6 +244,7 @@ int trajopt_gps_backward_pass_host(const double* Cxx_host, const double* cx_host
  *   quad_expectation  util.cpp:123-134 (mbgps.py:184-186)   E[x'Qx + x'q + q0] under N(mu, sigma)
  * status[p] = 1 when a sigma_ctl is not positive definite (Armadillo's inv_sympd() throws there), else 0.
  * augment_cost and kl_divergence launch one grid row per step: nb_steps < 65535 (TRAJOPT_ERR_BAD_ARG beyond). */
+/* The four other functions of the module take the same shapes as the backward pass (any dm_state <= 32, dm_act <= 16). */
 int trajopt_gps_forward_pass_batched(const double* mu_x0, const double* sigma_x0, const double* A, const double* B,
                                      const double* c, const double* sigma_dyn, const double* K, const double* kff,
                                      const double* sigma_ctl, int dm_state, int dm_act, int nb_steps,

@@ -10,6 +10,8 @@ pytestmark = pytest.mark.gpu
 OUT = ("Qxx", "Qux", "Quu", "qx", "qu", "q0", "V", "v", "v0", "K", "kff", "sigma_ctl")
 ARGS = ("Cxx", "cx", "Cuu", "cu", "Cxu", "c0", "A", "B", "c", "sigma_dyn", "alpha")
 SHAPES = [(2, 1), (3, 1), (4, 1), (6, 1), (2, 2), (4, 2)]
+FWD_OUT = ("mu_x", "sigma_x", "mu_u", "sigma_u", "mu_xu", "sigma_xu")
+AG_OUT = ("Cxx", "cx", "Cuu", "cu", "Cxu", "c0")
 
 
 def _run_gpu(stack, n, m, T, N, full=True):
@@ -113,6 +115,36 @@ def test_host_entry_point_is_the_reference_signature(oracle):
         core.backward_pass(*[q[k] for k in ARGS], n, m, T)
 
 
+def test_host_entry_points_take_any_dimensions(oracle):
+    """The pybind11-shaped host entries on a shape without an instantiated kernel (dx = 5, du = 3): the reference's
+    module takes any dimensions (gps/src/util.cpp:83-374)."""
+    from trajopt_amd.gps import core
+    from trajopt_amd import synthetic as S
+    n, m, T = 5, 3, 20
+    q = S.problem(S.gps_inputs(n, m, T, 1, seed=8), 0)
+    out = core.backward_pass(*[q[k] for k in ARGS], n, m, T)
+    ref, failed = oracle.gps_backward_pass(*[q[k] for k in ARGS], n, m, T)
+    assert out[12] == 0 and not failed
+    for k, a, r in zip(OUT, out[:12], ref[:12]):
+        assert_close(a, r, k)
+    K, kff, sg = ref[9], ref[10], ref[11]
+    rng = np.random.default_rng(3)
+    mu0, R = rng.standard_normal(n), rng.standard_normal((n, n))
+    s0 = 1e-2 * (R.T @ R / n + np.eye(n))
+    fw = core.forward_pass(mu0, s0, q["A"], q["B"], q["c"], q["sigma_dyn"], K, kff, sg, n, m, T)
+    fw_ref = oracle.gps_forward_pass(mu0, s0, q["A"], q["B"], q["c"], q["sigma_dyn"], K, kff, sg, n, m, T)
+    for k, a, r in zip(FWD_OUT, fw, fw_ref):
+        assert_close(a, r, k)
+    ag = core.augment_cost(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["c0"], K, kff, sg, q["alpha"], n, m, T)
+    ag_ref = oracle.gps_augment_cost(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["c0"], K, kff, sg, q["alpha"], n, m, T)
+    for k, a, r in zip(AG_OUT, ag, ag_ref):
+        assert_close(a, r, "ag" + k)
+    kl = core.kl_divergence(K + 0.1, kff - 0.1, 1.5 * sg, K, kff, sg, fw_ref[0], fw_ref[1], n, m, T)[0]
+    assert_close(kl, oracle.gps_kl_divergence(K + 0.1, kff - 0.1, 1.5 * sg, K, kff, sg, fw_ref[0], fw_ref[1], n, m, T), "kl")
+    qe = core.quad_expectation(mu0, s0, q["Cxx"][..., 0], q["cx"][:, 0], q["c0"][0])
+    assert abs(qe - oracle.gps_quad_expectation(mu0, s0, q["Cxx"][..., 0], q["cx"][:, 0], q["c0"][0])) <= 1e-9 * max(1.0, abs(qe))
+
+
 def test_unsupported_shapes_are_refused():
     from trajopt_amd._lib import lib
     assert lib().trajopt_gps_backward_supported(4, 1) == 1
@@ -121,8 +153,6 @@ def test_unsupported_shapes_are_refused():
 
 
 # ---- forward_pass, augment_cost, kl_divergence, quad_expectation (gps/src/util.cpp:83-269) ------------------------
-FWD_OUT = ("mu_x", "sigma_x", "mu_u", "sigma_u", "mu_xu", "sigma_xu")
-AG_OUT = ("Cxx", "cx", "Cuu", "cu", "Cxu", "c0")
 
 
 def _policies(oracle, stack, n, m, T, N, seed):
@@ -145,6 +175,16 @@ def _policies(oracle, stack, n, m, T, N, seed):
 @pytest.mark.parametrize("n,m", SHAPES)
 @pytest.mark.parametrize("T,N", [(30, 67), (6, 130)])
 def test_gps_forward_augment_kl_quadexp_match_oracle(oracle, n, m, T, N):
+    _check_ops(oracle, n, m, T, N)
+
+
+@pytest.mark.parametrize("n,m", [(5, 3), (12, 4), (3, 4), (8, 1), (16, 8), (1, 1)])
+def test_gps_forward_augment_kl_quadexp_any_dimensions(oracle, n, m):
+    """The same four functions on shapes without an instantiated kernel (gen_wave.hip: run-time dimensions)."""
+    _check_ops(oracle, n, m, 12, 7)
+
+
+def _check_ops(oracle, n, m, T, N):
     import torch
     from trajopt_amd import backward, layout as L, synthetic as S
     stack = S.gps_inputs(n, m, T, N, seed=777 + 10 * n + m)

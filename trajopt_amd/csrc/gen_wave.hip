@@ -241,6 +241,310 @@ int launch_gps_backward_generic(const trajopt_gps_backward_io_t& io, int n, int 
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// The other GPS functions for any dimensions (algebra as gps_ops.hip): forward_pass util.cpp:195-269, augment_cost
+// :136-193, kl_divergence :83-121 (one wave per problem / per (problem, step)), quad_expectation :123-134 (one thread
+// per problem, straight from global memory).
+// ----------------------------------------------------------------------------------------------------------------
+namespace gw {
+// One lane: inv_sympd() as Armadillo's Cholesky-based routine reads its argument - from the lower triangle; Xi = X^-1,
+// det = det X, false when a Cholesky pivot is not positive (Armadillo throws).  A, Y: m x m scratch.
+__device__ bool inv_sympd_serial(const double* X, int m, double* A, double* Y, double* Xi, double* det) {
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i < m; ++i) Y[i + m * j] = i >= j ? X[i + m * j] : X[j + m * i];
+    bool pd = true;
+    for (int j = 0; j < m; ++j) {   // pivots of the Cholesky factorisation (A as work space)
+        double d = Y[j + m * j];
+        for (int k = 0; k < j; ++k) d = fma(-A[j + m * k], A[j + m * k], d);
+        pd = pd && (d > 0.0);
+        const double sd = sqrt(d);
+        A[j + m * j] = sd;
+        for (int i = j + 1; i < m; ++i) {
+            double x = Y[i + m * j];
+            for (int k = 0; k < j; ++k) x = fma(-A[i + m * k], A[j + m * k], x);
+            A[i + m * j] = x / sd;
+        }
+    }
+    inv_serial(Y, m, A, Xi, det);
+    return pd;
+}
+}  // namespace gw
+
+struct GpsFwdGenArgs {
+    const double *mu_x0, *sigma_x0, *A, *B, *c, *sigma_dyn, *K, *kff, *sigma_ctl;
+    double *mu_x, *sigma_x, *mu_u, *sigma_u, *mu_xu, *sigma_xu;
+    size_t NP;
+    int n, m, T;
+};
+
+__global__ __launch_bounds__(64) void gps_forward_generic_kernel(GpsFwdGenArgs a) {
+    using namespace gw;
+    extern __shared__ __align__(16) double sm[];
+    const int n = a.n, m = a.m, T = a.T, nn = n * n, nm = n * m, mm2 = m * m, W = n + m;
+    const int lane = threadIdx.x;
+    const Acc x{a.NP, (size_t)blockIdx.x};
+    double* ptr = sm;
+    auto take = [&](int k) { double* r = ptr; ptr += k; return r; };
+    double *mx = take(n), *sx = take(nn), *A = take(nn), *B = take(nm), *c = take(n), *S = take(nn), *K = take(nm);
+    double *k = take(m), *Sc = take(mm2), *mu = take(m), *ksx = take(nm), *sxk = take(nm), *raw = take(mm2), *su = take(mm2);
+    double *J = take(W * W), *mxu = take(W), *FJ = take(n * W), *sn = take(nn), *mn = take(n);
+    auto F = [&](int i, int kk) -> double { return kk < n ? A[i + n * kk] : B[i + n * (kk - n)]; };
+    g2l(mx, a.mu_x0, n, 0, x, lane);
+    g2l(sx, a.sigma_x0, nn, 0, x, lane);
+    __syncthreads();
+    l2g(a.mu_x, n, 0, x, mx, lane);
+    l2g(a.sigma_x, nn, 0, x, sx, lane);
+    for (int t = 0; t < T; ++t) {
+        g2l(A, a.A, nn, t, x, lane); g2l(B, a.B, nm, t, x, lane); g2l(c, a.c, n, t, x, lane);
+        g2l(S, a.sigma_dyn, nn, t, x, lane); g2l(K, a.K, nm, t, x, lane); g2l(k, a.kff, m, t, x, lane);
+        g2l(Sc, a.sigma_ctl, mm2, t, x, lane);
+        __syncthreads();
+        for (int j = lane; j < m; j += kW) {   // :229
+            double acc = 0.0;
+            for (int q = 0; q < n; ++q) acc = fma(K[j + m * q], mx[q], acc);
+            mu[j] = acc + k[j];
+        }
+        mm(ksx, m, n, n, K, m, false, sx, n, false, 1.0, nullptr, 0.0, lane);   // K sx
+        mm(sxk, n, m, n, sx, n, false, K, m, true, 1.0, nullptr, 0.0, lane);    // sx K'
+        __syncthreads();
+        mm(raw, m, m, n, ksx, m, false, K, m, true, 1.0, Sc, 1.0, lane);        // :232
+        __syncthreads();
+        for (int e = lane; e < mm2; e += kW) su[e] = 0.5 * (raw[e] + raw[(e / m) + m * (e % m)]);   // :233
+        __syncthreads();
+        // J = sym([[sx, sx K'], [K sx, su]])   (:237-239), column-major W x W
+        for (int e = lane; e < W * W; e += kW) {
+            const int i = e % W, j = e / W;
+            double v;
+            if (i < n && j < n) v = 0.5 * (sx[i + n * j] + sx[j + n * i]);
+            else if (i < n) v = 0.5 * (sxk[i + n * (j - n)] + ksx[(j - n) + m * i]);
+            else if (j < n) v = 0.5 * (sxk[j + n * (i - n)] + ksx[(i - n) + m * j]);
+            else v = 0.5 * (su[(i - n) + m * (j - n)] + su[(j - n) + m * (i - n)]);
+            J[e] = v;
+        }
+        for (int i = lane; i < W; i += kW) mxu[i] = i < n ? mx[i] : mu[i - n];
+        __syncthreads();
+        l2g(a.mu_u, m, t, x, mu, lane); l2g(a.sigma_u, mm2, t, x, su, lane);
+        l2g(a.mu_xu, W, t, x, mxu, lane); l2g(a.sigma_xu, W * W, t, x, J, lane);
+        for (int e = lane; e < n * W; e += kW) {   // F J, F = [A B]
+            const int i = e % n, j = e / n;
+            double acc = 0.0;
+            for (int q = 0; q < W; ++q) acc = fma(F(i, q), J[q + W * j], acc);
+            FJ[e] = acc;
+        }
+        __syncthreads();
+        for (int e = lane; e < nn; e += kW) {      // :246-251
+            const int i = e % n, j = e / n;
+            double acc = 0.0;
+            for (int q = 0; q < W; ++q) acc = fma(FJ[i + n * q], F(j, q), acc);
+            sn[e] = S[e] + acc;
+        }
+        for (int i = lane; i < n; i += kW) {
+            double acc = 0.0;
+            for (int q = 0; q < W; ++q) acc = fma(F(i, q), mxu[q], acc);
+            mn[i] = acc + c[i];
+        }
+        __syncthreads();
+        for (int e = lane; e < nn; e += kW) sx[e] = 0.5 * (sn[e] + sn[(e / n) + n * (e % n)]);
+        for (int i = lane; i < n; i += kW) mx[i] = mn[i];
+        __syncthreads();
+        l2g(a.mu_x, n, t + 1, x, mx, lane);
+        l2g(a.sigma_x, nn, t + 1, x, sx, lane);
+    }
+    // last slices (:253-256): [mu_x; 0] and the state block only
+    for (int i = lane; i < W; i += kW) mxu[i] = i < n ? mx[i] : 0.0;
+    for (int e = lane; e < W * W; e += kW) J[e] = (e % W < n && e / W < n) ? sx[(e % W) + n * (e / W)] : 0.0;
+    __syncthreads();
+    l2g(a.mu_xu, W, T, x, mxu, lane);
+    l2g(a.sigma_xu, W * W, T, x, J, lane);
+}
+
+struct GpsAugGenArgs {
+    const double *Cxx, *cx, *Cuu, *cu, *Cxu, *c0, *K, *kff, *sigma_ctl, *alpha;
+    double *agCxx, *agcx, *agCuu, *agcu, *agCxu, *agc0;
+    int32_t* status;
+    size_t NP;
+    int n, m, T;
+};
+
+__global__ __launch_bounds__(64) void gps_augment_generic_kernel(GpsAugGenArgs a) {
+    using namespace gw;
+    extern __shared__ __align__(16) double sm[];
+    const int n = a.n, m = a.m, T = a.T, nn = n * n, nm = n * m, mm2 = m * m, t = blockIdx.y;
+    const int lane = threadIdx.x;
+    const Acc x{a.NP, (size_t)blockIdx.x};
+    double* ptr = sm;
+    auto take = [&](int k) { double* r = ptr; ptr += k; return r; };
+    double *Cxx = take(nn), *cx = take(n), *Cuu = take(mm2), *cu = take(m), *Cxu = take(nm), *K = take(nm), *k = take(m);
+    double *sg = take(mm2), *lam = take(mm2), *w1 = take(mm2), *w2 = take(mm2), *KtL = take(nm), *Lk = take(m), *flag = take(2);
+    double *oCxx = take(nn);
+    g2l(Cxx, a.Cxx, nn, t, x, lane); g2l(cx, a.cx, n, t, x, lane); g2l(Cuu, a.Cuu, mm2, t, x, lane);
+    g2l(cu, a.cu, m, t, x, lane); g2l(Cxu, a.Cxu, nm, t, x, lane);
+    double c0 = gl(a.c0, 1, t, 0, x);
+    if (t < T) {   // (block-uniform)
+        g2l(K, a.K, nm, t, x, lane); g2l(k, a.kff, m, t, x, lane); g2l(sg, a.sigma_ctl, mm2, t, x, lane);
+        const double al = gl(a.alpha, 1, t, 0, x), ha = 0.5 * al;
+        __syncthreads();
+        if (lane == 0) {
+            double det = 0.0;
+            const bool pd = inv_sympd_serial(sg, m, w1, w2, lam, &det);   // inv_sympd() throws in the reference (:164)
+            if (!pd) a.status[x.p] = 1;
+            flag[0] = det;
+        }
+        __syncthreads();
+        mm(KtL, n, m, m, K, m, true, lam, m, false, 1.0, nullptr, 0.0, lane);   // K' lam
+        for (int j = lane; j < m; j += kW) {
+            double acc = 0.0;
+            for (int q = 0; q < m; ++q) acc = fma(lam[j + m * q], k[q], acc);
+            Lk[j] = acc;
+        }
+        __syncthreads();
+        mm(oCxx, n, n, m, KtL, n, false, K, m, false, ha, Cxx, 1.0, lane);       // :166
+        double kLk = 0.0;
+        for (int j = 0; j < m; ++j) kLk = fma(k[j], Lk[j], kLk);
+        __syncthreads();
+        for (int e = lane; e < nn; e += kW) Cxx[e] = oCxx[e];
+        for (int e = lane; e < mm2; e += kW) Cuu[e] = fma(ha, lam[e], Cuu[e]);   // :167
+        for (int e = lane; e < nm; e += kW) Cxu[e] = fma(-ha, KtL[e], Cxu[e]);   // :168
+        for (int i = lane; i < n; i += kW) {                                     // :169
+            double acc = 0.0;
+            for (int q = 0; q < m; ++q) acc = fma(KtL[i + n * q], k[q], acc);
+            cx[i] = fma(al, acc, cx[i]);
+        }
+        for (int j = lane; j < m; j += kW) cu[j] = fma(-al, Lk[j], cu[j]);       // :170
+        c0 = c0 + ha * (m * 1.8378770664093453 + log(flag[0])) + ha * kLk;       // :171-172
+    }
+    __syncthreads();
+    l2g(a.agCxx, nn, t, x, Cxx, lane); l2g(a.agcx, n, t, x, cx, lane); l2g(a.agCuu, mm2, t, x, Cuu, lane);
+    l2g(a.agcu, m, t, x, cu, lane); l2g(a.agCxu, nm, t, x, Cxu, lane);
+    if (lane == 0) a.agc0[(size_t)t * x.NP + x.p] = c0;
+}
+
+struct GpsKlGenArgs {
+    const double *pK, *pk, *pS, *qK, *qk, *qS, *mu_x, *sigma_x;
+    double* kl;
+    int32_t* status;
+    size_t NP;
+    int n, m, T;
+};
+
+__global__ __launch_bounds__(64) void gps_kl_generic_kernel(GpsKlGenArgs a) {
+    using namespace gw;
+    extern __shared__ __align__(16) double sm[];
+    const int n = a.n, m = a.m, nn = n * n, nm = n * m, mm2 = m * m, t = blockIdx.y;
+    const int lane = threadIdx.x;
+    const Acc x{a.NP, (size_t)blockIdx.x};
+    double* ptr = sm;
+    auto take = [&](int k) { double* r = ptr; ptr += k; return r; };
+    double *dK = take(nm), *dk = take(m), *pS = take(mm2), *qS = take(mm2), *mu = take(n), *sx = take(nn);
+    double *lam = take(mm2), *w1 = take(mm2), *w2 = take(mm2), *w3 = take(mm2), *LdK = take(nm), *Ldk = take(m), *flag = take(2);
+    for (int e = lane; e < nm; e += kW) dK[e] = gl(a.qK, nm, t, e, x) - gl(a.pK, nm, t, e, x);
+    for (int j = lane; j < m; j += kW) dk[j] = -gl(a.qk, m, t, j, x) + gl(a.pk, m, t, j, x);
+    g2l(pS, a.pS, mm2, t, x, lane); g2l(qS, a.qS, mm2, t, x, lane); g2l(mu, a.mu_x, n, t, x, lane); g2l(sx, a.sigma_x, nn, t, x, lane);
+    __syncthreads();
+    if (lane == 0) {
+        double detq = 0.0, detp = 0.0;
+        const bool pd = inv_sympd_serial(qS, m, w1, w2, lam, &detq);   // :102
+        if (!pd) a.status[x.p] = 1;
+        inv_serial(pS, m, w1, w3, &detp);                              // det(p_sigma)
+        flag[0] = detq;
+        flag[1] = detp;
+    }
+    __syncthreads();
+    mm(LdK, m, n, m, lam, m, false, dK, m, false, 1.0, nullptr, 0.0, lane);
+    for (int j = lane; j < m; j += kW) {
+        double acc = 0.0;
+        for (int q = 0; q < m; ++q) acc = fma(lam[j + m * q], dk[q], acc);
+        Ldk[j] = acc;
+    }
+    __syncthreads();
+    // diff_K = dK' lam dK (n x n); trace(diff_K sx), mu' diff_K mu, mu' dK' lam dk, dk' lam dk, trace(lam pS)
+    double part = 0.0;
+    for (int e = lane; e < nn; e += kW) {
+        const int i = e % n, j = e / n;
+        double d = 0.0;
+        for (int q = 0; q < m; ++q) d = fma(dK[q + m * i], LdK[q + m * j], d);
+        part = fma(0.5 * d, sx[j + n * i], part);
+        part = fma(0.5 * mu[i] * d, mu[j], part);
+    }
+    for (int i = lane; i < n; i += kW) {
+        double d = 0.0;
+        for (int q = 0; q < m; ++q) d = fma(dK[q + m * i], Ldk[q], d);
+        part = fma(-mu[i], d, part);
+    }
+    for (int j = lane; j < m; j += kW) part = fma(0.5 * dk[j], Ldk[j], part);
+    for (int e = lane; e < mm2; e += kW) part = fma(0.5 * lam[(e % m) + m * (e / m)], pS[(e / m) + m * (e % m)], part);
+    const double sum = wsum(part);
+    if (lane == 0) a.kl[(size_t)t * x.NP + x.p] = 0.5 * log(flag[0] / flag[1]) - 0.5 * m + sum;
+}
+
+__global__ __launch_bounds__(64) void gps_quadexp_generic_kernel(const double* mu, const double* sg, const double* Q,
+                                                                  const double* q, const double* q0, double* out,
+                                                                  size_t NP, int n) {
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (p >= NP) return;
+    double quad = 0.0, lin = 0.0, trc = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) {
+            s = fma(mu[(size_t)i * NP + p], Q[((size_t)i + (size_t)n * j) * NP + p], s);
+            trc = fma(Q[((size_t)j + (size_t)n * i) * NP + p], sg[((size_t)i + (size_t)n * j) * NP + p], trc);
+        }
+        quad = fma(s, mu[(size_t)j * NP + p], quad);
+        lin = fma(mu[(size_t)j * NP + p], q[(size_t)j * NP + p], lin);
+    }
+    out[p] = quad + lin + q0[p] + trc;   // :132
+}
+
+int launch_gps_forward_generic(const double* mu_x0, const double* sigma_x0, const double* A, const double* B,
+                               const double* c, const double* sigma_dyn, const double* K, const double* kff,
+                               const double* sigma_ctl, int n, int m, int T, int64_t NP, double* mu_x, double* sigma_x,
+                               double* mu_u, double* sigma_u, double* mu_xu, double* sigma_xu, hipStream_t st) {
+    if (!gps_generic_shape_ok(n, m)) return TRAJOPT_ERR_UNSUPPORTED;
+    GpsFwdGenArgs a{mu_x0, sigma_x0, A, B, c, sigma_dyn, K, kff, sigma_ctl, mu_x, sigma_x, mu_u, sigma_u, mu_xu, sigma_xu,
+                    (size_t)NP, n, m, T};
+    const int W = n + m;
+    const size_t lds = sizeof(double) * (size_t)(4 * n * n + 4 * n * m + 3 * m * m + 3 * n + 2 * m + W * W + W + n * W);
+    TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)gps_forward_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gps_forward_generic_kernel, dim3((unsigned)NP), dim3(64), lds, st, a);
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+int launch_gps_augment_generic(const double* Cxx, const double* cx, const double* Cuu, const double* cu, const double* Cxu,
+                               const double* c0, const double* K, const double* kff, const double* sigma_ctl,
+                               const double* alpha, int n, int m, int T, int64_t NP, double* agCxx, double* agcx,
+                               double* agCuu, double* agcu, double* agCxu, double* agc0, int32_t* status, hipStream_t st) {
+    if (!gps_generic_shape_ok(n, m) || T + 1 > 65535) return TRAJOPT_ERR_UNSUPPORTED;
+    GpsAugGenArgs a{Cxx, cx, Cuu, cu, Cxu, c0, K, kff, sigma_ctl, alpha, agCxx, agcx, agCuu, agcu, agCxu, agc0, status,
+                    (size_t)NP, n, m, T};
+    const size_t lds = sizeof(double) * (size_t)(2 * n * n + 3 * n * m + 5 * m * m + n + 3 * m + 2);
+    TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)gps_augment_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gps_augment_generic_kernel, dim3((unsigned)NP, (unsigned)(T + 1)), dim3(64), lds, st, a);
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+int launch_gps_kl_generic(const double* pK, const double* pk, const double* pS, const double* qK, const double* qk,
+                          const double* qS, const double* mu_x, const double* sigma_x, int n, int m, int T, int64_t NP,
+                          double* kl, int32_t* status, hipStream_t st) {
+    if (!gps_generic_shape_ok(n, m) || T > 65535) return TRAJOPT_ERR_UNSUPPORTED;
+    GpsKlGenArgs a{pK, pk, pS, qK, qk, qS, mu_x, sigma_x, kl, status, (size_t)NP, n, m, T};
+    const size_t lds = sizeof(double) * (size_t)(n * n + 2 * n * m + 6 * m * m + n + 2 * m + 2);
+    TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)gps_kl_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gps_kl_generic_kernel, dim3((unsigned)NP, (unsigned)T), dim3(64), lds, st, a);
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+int launch_gps_quadexp_generic(const double* mu, const double* sg, const double* Q, const double* q, const double* q0,
+                               double* out, int n, int64_t NP, hipStream_t st) {
+    if (n < 1 || n > 64) return TRAJOPT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gps_quadexp_generic_kernel, dim3((unsigned)((NP + 63) / 64)), dim3(64), 0, st, mu, sg, Q, q, q0, out,
+                       (size_t)NP, n);
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // Belief-space iLQR backward pass, bspilqr/src/util.cpp:83-204 (algebra and quirks as bsp_tpp.hip / oracle/bsp_oracle.hpp)
 // ----------------------------------------------------------------------------------------------------------------
 struct BspGenArgs {

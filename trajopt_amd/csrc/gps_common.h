@@ -57,6 +57,19 @@ inline bool gps_shape_supported(int n, int m) {
 // gen_wave.hip: wave-per-problem kernels with run-time dimensions for the shapes without an instantiation
 bool gps_generic_shape_ok(int n, int m);
 int launch_gps_backward_generic(const trajopt_gps_backward_io_t& io, int n, int m, int T, int64_t NP, hipStream_t st);
+int launch_gps_forward_generic(const double* mu_x0, const double* sigma_x0, const double* A, const double* B,
+                               const double* c, const double* sigma_dyn, const double* K, const double* kff,
+                               const double* sigma_ctl, int n, int m, int T, int64_t NP, double* mu_x, double* sigma_x,
+                               double* mu_u, double* sigma_u, double* mu_xu, double* sigma_xu, hipStream_t st);
+int launch_gps_augment_generic(const double* Cxx, const double* cx, const double* Cuu, const double* cu, const double* Cxu,
+                               const double* c0, const double* K, const double* kff, const double* sigma_ctl,
+                               const double* alpha, int n, int m, int T, int64_t NP, double* agCxx, double* agcx,
+                               double* agCuu, double* agcu, double* agCxu, double* agc0, int32_t* status, hipStream_t st);
+int launch_gps_kl_generic(const double* pK, const double* pk, const double* pS, const double* qK, const double* qk,
+                          const double* qS, const double* mu_x, const double* sigma_x, int n, int m, int T, int64_t NP,
+                          double* kl, int32_t* status, hipStream_t st);
+int launch_gps_quadexp_generic(const double* mu, const double* sg, const double* Q, const double* q, const double* q0,
+                               double* out, int n, int64_t NP, hipStream_t st);
 bool bsp_generic_shape_ok(int b, int m);
 int launch_bsp_backward_generic(const trajopt_bsp_backward_io_t& io, int reg, int tau_mode, int b, int m, int T,
                                 int64_t NP, hipStream_t st);

@@ -428,8 +428,9 @@ int trajopt_gps_forward_pass_batched(const double* mu_x0, const double* sigma_x0
                  (size_t)NP, T};
     const dim3 grid((unsigned)((NP + 63) / 64)), block(64);
     hipStream_t st = as_stream(stream);
-    if (!gps_dispatch(n, m, LaunchFwd{a, grid, st}))
-        return TRAJOPT_ERR_UNSUPPORTED;
+    if (!gps_dispatch(n, m, LaunchFwd{a, grid, st}))   // any other dx <= 32, du <= 16: gen_wave.hip
+        return launch_gps_forward_generic(mu_x0, sigma_x0, A, B, c, sigma_dyn, K, kff, sigma_ctl, n, m, T, NP, mu_x, sigma_x,
+                                          mu_u, sigma_u, mu_xu, sigma_xu, st);
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
 }
@@ -449,7 +450,8 @@ int trajopt_gps_augment_cost_batched(const double* Cxx, const double* cx, const 
     hipStream_t st = as_stream(stream);
     TRAJOPT_HIP_CHECK(hipMemsetAsync(status, 0, (size_t)NP * sizeof(int32_t), st));
     if (!gps_dispatch(n, m, LaunchAug{a, grid, st}))
-        return TRAJOPT_ERR_UNSUPPORTED;
+        return launch_gps_augment_generic(Cxx, cx, Cuu, cu, Cxu, c0, K, kff, sigma_ctl, alpha, n, m, T, NP, agCxx, agcx,
+                                          agCuu, agcu, agCxu, agc0, status, st);
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
 }
@@ -467,7 +469,8 @@ int trajopt_gps_kl_divergence_batched(const double* p_K, const double* p_kff, co
     hipStream_t st = as_stream(stream);
     TRAJOPT_HIP_CHECK(hipMemsetAsync(status, 0, (size_t)NP * sizeof(int32_t), st));
     if (!gps_dispatch(n, m, LaunchKl{a, grid, st}))
-        return TRAJOPT_ERR_UNSUPPORTED;
+        return launch_gps_kl_generic(p_K, p_kff, p_sigma_ctl, q_K, q_kff, q_sigma_ctl, mu_x, sigma_x, n, m, T, NP, kl,
+                                     status, st);
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
 }
@@ -483,7 +486,7 @@ int trajopt_gps_quad_expectation_batched(const double* mu, const double* sigma_s
         case 3: hipLaunchKernelGGL((gps_quadexp_kernel<3>), grid, block, 0, st, mu, sigma_s, Q, q, q0, out, (size_t)NP); break;
         case 4: hipLaunchKernelGGL((gps_quadexp_kernel<4>), grid, block, 0, st, mu, sigma_s, Q, q, q0, out, (size_t)NP); break;
         case 6: hipLaunchKernelGGL((gps_quadexp_kernel<6>), grid, block, 0, st, mu, sigma_s, Q, q, q0, out, (size_t)NP); break;
-        default: return TRAJOPT_ERR_UNSUPPORTED;
+        default: return launch_gps_quadexp_generic(mu, sigma_s, Q, q, q0, out, n, NP, st);
     }
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
@@ -499,7 +502,7 @@ int trajopt_gps_forward_pass_host(const double* mu_x0, const double* sigma_x0, c
         !sigma_u || !mu_xu || !sigma_xu || n <= 0 || m <= 0 || T <= 0)
         return TRAJOPT_ERR_BAD_ARG;
     if (trajopt_device_count() < 0) return TRAJOPT_ERR_NO_DEVICE;
-    if (!gps_shape_supported(n, m)) return TRAJOPT_ERR_UNSUPPORTED;
+    if (!gps_shape_supported(n, m) && !gps_generic_shape_ok(n, m)) return TRAJOPT_ERR_UNSUPPORTED;
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m, w = n + m, T1 = (size_t)T + 1;
     HostStage s;
     GPS_TRY(s.init(n + nn + (2 * nn + 2 * nm + n + m + mm) * T + (n + nn + w + w * w) * T1 + (m + mm) * T));
@@ -522,7 +525,7 @@ int trajopt_gps_augment_cost_host(const double* Cxx, const double* cx, const dou
         !agcu || !agCxu || !agc0 || !status || n <= 0 || m <= 0 || T <= 0)
         return TRAJOPT_ERR_BAD_ARG;
     if (trajopt_device_count() < 0) return TRAJOPT_ERR_NO_DEVICE;
-    if (!gps_shape_supported(n, m)) return TRAJOPT_ERR_UNSUPPORTED;
+    if (!gps_shape_supported(n, m) && !gps_generic_shape_ok(n, m)) return TRAJOPT_ERR_UNSUPPORTED;
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m, T1 = (size_t)T + 1;
     const size_t per = nn + n + mm + m + nm + 1;
     HostStage s;
@@ -551,7 +554,7 @@ int trajopt_gps_kl_divergence_host(const double* p_K, const double* p_kff, const
         n <= 0 || m <= 0 || T <= 0)
         return TRAJOPT_ERR_BAD_ARG;
     if (trajopt_device_count() < 0) return TRAJOPT_ERR_NO_DEVICE;
-    if (!gps_shape_supported(n, m)) return TRAJOPT_ERR_UNSUPPORTED;
+    if (!gps_shape_supported(n, m) && !gps_generic_shape_ok(n, m)) return TRAJOPT_ERR_UNSUPPORTED;
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
     HostStage s;
     // mu_x / sigma_x may hold T + 1 slices (mbgps.py:198-201 passes xdist.mu, xdist.sigma); the first T are read
@@ -575,7 +578,7 @@ int trajopt_gps_quad_expectation_host(const double* mu, const double* sigma_s, c
                                       double q0, int n, double* result) {
     if (!mu || !sigma_s || !Q || !q || !result || n <= 0) return TRAJOPT_ERR_BAD_ARG;
     if (trajopt_device_count() < 0) return TRAJOPT_ERR_NO_DEVICE;
-    if (n != 2 && n != 3 && n != 4 && n != 6) return TRAJOPT_ERR_UNSUPPORTED;
+    if (n > 64) return TRAJOPT_ERR_UNSUPPORTED;
     const size_t nn = (size_t)n * n;
     HostStage s;
     GPS_TRY(s.init(2 * nn + 2 * n + 2));
