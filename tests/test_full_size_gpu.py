@@ -251,3 +251,41 @@ def test_sharded_ilqr_two_ranks_equal_one_rank():
         assert np.array_equal(it, want["iters"])
         assert prog["total_cost"] == pytest.approx(float(want["last_return"].sum()), rel=1e-12)
         assert prog["nb_stopped"] == int((want["status"] != 0).sum())
+
+
+@pytest.mark.parametrize("name,kw", [("cartpole", dict(dt=0.02, uw=[1e-5])),
+                                     ("pendulum", dict(dt=0.05, uw=[1e-3], slew_rate=True, periodic=True))])
+def test_lane_fused_quadratise_backward_at_32768_problems(oracle, name, kw):
+    """Batches of >= 32 768 pendulums / cartpoles take quadratisation + backward pass as ONE lane-per-problem launch
+    (plan fused_quad_bwd = 2, bwd_tpp.hip): same iterates as the two-launch path on every problem, and as the oracle's
+    driver (ilqr.py:136-237) on a sample - with the stopping rules on, so that stopped problems, rejected steps and the
+    lambda retry loop all occur inside the batch."""
+    from tests.test_ilqr_gpu import _pair
+    from trajopt_amd.ilqr import BatchedILQR
+    pe, oe = _pair(name, **kw)
+    N, T, iters = 32768, 24, 4
+    rng = np.random.Generator(np.random.PCG64(11))
+    x0 = np.asarray(pe.x0)[None] + 0.3 * rng.standard_normal((N, pe.dm_state))
+    kff0 = 1e-2 * rng.standard_normal((N, pe.dm_act, T))
+    runs = {}
+    for fusion in (True, False):
+        s = BatchedILQR(pe, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False, no_fusion=not fusion)
+        assert s.plan()["fused_quad_bwd"] == (2 if fusion else 0)
+        traces = s.run(nb_iter=iters)
+        runs[fusion] = dict(traces=traces, **{k: s.host(k) for k in ("xref", "uref", "K", "kff", "lmbda", "dlmbda", "status",
+                                                                    "iters", "last_return", "alpha")})
+    a, b = runs[True], runs[False]
+    assert a["traces"] == b["traces"]
+    for k in ("xref", "uref", "K", "kff", "lmbda", "dlmbda", "status", "iters", "last_return"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["alpha"], b["alpha"], equal_nan=True)
+    if name == "cartpole":
+        assert len({len(t) for t in a["traces"]}) > 1      # the batch really mixes accepting and rejecting problems
+    for p in list(range(0, N, 2731)) + [N - 1]:
+        r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=iters)
+        assert len(a["traces"][p]) == len(r["trace"]), (p, a["traces"][p], r["trace"])
+        assert_close(np.array(a["traces"][p]), r["trace"], "trace[%d]" % p)
+        assert a["status"][p] == r["status"] and a["iters"][p] == r["iters"]
+        assert_close(a["xref"][p], r["xref"], "xref", tol=1e-8)
+        if len(r["trace"]) > 1:
+            assert_close(a["K"][p], r["K"], "K", tol=1e-8)

@@ -9,6 +9,7 @@
 // named input register sets: the loads of step t-1 are issued before the arithmetic of step t, so
 // HBM latency hides under the ~250 dependent fp64 FMAs of a step.
 #include "smallmat.h"
+#include "sys.h"
 
 namespace trajopt {
 
@@ -398,6 +399,213 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
             a.io.g_norm[p] = g / M;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Quadratisation + backward pass in one launch for LARGE batches of dx <= 4, du = 1 models (65 536 cartpoles), lane =
+// problem.  As two launches the expansion A, B, cx, cu makes a round trip through HBM - 200 of the 280 bytes the
+// quadratisation moves per problem-step and 200 of the 250 the recursion reads (cartpole, structured cost) - and both
+// phases are HBM-bound at that size.  Here a lane walks its problem back in time: state and action of step t (fetched a
+// step ahead, from the time-blocked candidate plane ref_plane[p] or the dense reference, and written through like
+// fused_qb4.hip does) go through the dual-number expansion (objects.py:68-78,114-117) in registers and straight into
+// bwd_step().  65 536 problems are 1024 waves: one per SIMD, each a chain of 500 x ~1900 instructions, all of them
+// arithmetic the two-launch path issues as well.  Small batches keep fused_qb4.hip (four problems per wave).
+struct FusedTppArgs {
+    TppArgs t;
+    trajopt_env_t env;
+    const double *xref, *uref;
+    RefView rv;
+};
+
+typedef unsigned ft_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ft_st(double x, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ft_v2u, x), r, off, 0, 0);
+}
+constexpr unsigned kFtNoStore = 0xfffffff8u;
+
+template <class SYS, bool GN>
+__global__ __launch_bounds__(64) void fused_tpp_kernel(FusedTppArgs fa) {
+    constexpr int N = SYS::N, M = SYS::M;
+    static_assert(M == 1 && N >= 2 && N <= 4, "lane-per-problem fused form: dx <= 4, du = 1");
+    const TppArgs& a = fa.t;
+    const trajopt_env_t& e = fa.env;
+    const size_t p0 = (size_t)blockIdx.x * 64;
+    const unsigned lane = threadIdx.x;
+    const size_t p = p0 + lane;
+    if (p >= a.NP) return;
+    if (a.io.active && a.io.active[p] == 0) return;
+    const size_t NP = a.NP;
+    const int T = a.T;
+    const Lane off{lane * 8u, NP};
+    const int kmul = a.io.out_bank ? TRAJOPT_GAIN_BANKS : 1;
+    const unsigned bank = (unsigned)gains_bank(a.io.out_bank, p);
+    const Lane offK{lane * 8u + bank * (unsigned)(N * M * NP * 8), NP}, offkff{lane * 8u + bank * (unsigned)(M * NP * 8), NP};
+    double lam = a.io.lmbda[p];
+    double dlam = (a.retry && a.io.dlmbda) ? a.io.dlmbda[p] : 1.0;
+    int div = -1, retries = 0;
+    double dV0 = 0.0, dV1 = 0.0;
+    double gmax[M];
+    // the reference trajectory: time-blocked candidate plane ref_plane[p] (common.h) when that is >= 0, else dense
+    int sel = -1;
+    if (fa.rv.ref_plane) sel = fa.rv.ref_plane[p];
+    const bool refp = sel >= 0;
+    const double* xsrc = refp ? fa.rv.cand_state + (size_t)sel * tb_plane(N, T + 1, NP) : fa.xref;
+    const double* usrc = refp ? fa.rv.cand_action + (size_t)sel * tb_plane(M, T, NP) : fa.uref;
+    auto xi = [&](int t, int i) { return refp ? tb_index(N, t, i, p, NP) : ((size_t)N * t + i) * NP + p; };
+    auto ui = [&](int t) { return refp ? tb_index(M, t, 0, p, NP) : (size_t)t * NP + p; };
+    // what is read from a plane is written through to the dense arrays (first sweep), with unconditional stores:
+    // a lane with nothing to write passes an offset beyond the range (see fused_qb4.hip on the wait-count pass)
+    const bool have_out = fa.rv.xref_out != nullptr && fa.rv.uref_out != nullptr;
+    const bool through = have_out && refp;
+    const __amdgpu_buffer_rsrc_t rxo = __builtin_amdgcn_make_buffer_rsrc(have_out ? fa.rv.xref_out : a.io.kff, 0,
+                                                                         have_out ? (unsigned)((size_t)N * (T + 1) * NP * 8) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ruo = __builtin_amdgcn_make_buffer_rsrc(have_out ? fa.rv.uref_out : a.io.kff, 0,
+                                                                         have_out ? (unsigned)((size_t)M * T * NP * 8) : 0u, 0x00020000);
+    const double sc = e.cost_times_dt ? e.dt : 1.0;
+    bool first = true;
+
+    for (;;) {
+        div = -1;
+        dV0 = 0.0;
+        dV1 = 0.0;
+        gmax[0] = -INFINITY;
+        double V[N * N], v[N];
+        {
+            // terminal condition (util.cpp:123-124) from the closed-form cost expansion at x_T (objects.py:72-78)
+            const double wT = a.io.cost_w[T];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double xT = xsrc[xi(T, i)];
+                double g = 0.0;
+                if (wT != 0.0) {
+                    const double y = ((e.periodic >> i) & 1) ? wrap_angle(xT) : xT;
+                    g = (wT * a.io.cost_gxx[i]) * (y - e.goal[i]);
+                }
+                v[i] = g;
+                if (first && through) fa.rv.xref_out[((size_t)N * T + i) * NP + p] = xT;   // x_T is not part of the loop
+#pragma unroll
+                for (int j = 0; j < N; ++j) V[i + N * j] = (i == j) ? wT * a.io.cost_gxx[i] : 0.0;
+            }
+        }
+        double nx[N], nu, nul, nw;
+        auto fetch = [&](int t) {   // unconditional, index clamped
+            t = t < 0 ? 0 : t;
+            const int tl = t >= 1 ? t - 1 : 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) nx[i] = xsrc[xi(t, i)];
+            nu = usrc[ui(t)];
+            nul = usrc[ui(tl)];
+            nw = a.io.cost_w[t];
+        };
+        fetch(T - 1);
+        for (int t = T - 1; t >= 0; --t) {
+            double x[N], u[M];
+#pragma unroll
+            for (int i = 0; i < N; ++i) x[i] = nx[i];
+            u[0] = nu;
+            const double ul = (e.slew_rate && t >= 1) ? nul : 0.0, w = nw;
+            fetch(t - 1);
+            const bool wt = through && first;
+            ft_st(u[0], ruo, wt ? (unsigned)(((size_t)t * NP + p) * 8) : kFtNoStore);
+#pragma unroll
+            for (int i = 0; i < N; ++i) ft_st(x[i], rxo, wt ? (unsigned)((((size_t)N * t + i) * NP + p) * 8) : kFtNoStore);
+            StepIn<N, M> in;
+            {
+                double J[N][N + M];
+                SYS::template jacobian_cols<N + M>(e, x, u, 0, J);
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+#pragma unroll
+                    for (int i = 0; i < N; ++i) in.A[i + N * k] = J[i][k];
+#pragma unroll
+                for (int i = 0; i < N; ++i) in.B[i] = J[i][N];
+            }
+            // cost expansion (objects.py:72-78), closed form for identity features
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double g = 0.0;
+                if (w != 0.0) {
+                    const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
+                    g = (w * (sc * 2.0 * e.gw[i])) * (y - e.goal[i]);
+                }
+                in.cx[i] = g;
+#pragma unroll
+                for (int j = 0; j < N; ++j) in.Cxx[i + N * j] = (i == j) ? w * a.io.cost_gxx[i] : 0.0;
+                in.Cxu[i] = 0.0;
+            }
+            in.cu[0] = sc * 2.0 * e.uw[0] * (e.slew_rate ? (u[0] - ul) : u[0]);
+            in.Cuu[0] = a.io.cost_guu[0];
+            in.ur[0] = u[0];
+            if (!bwd_step<N, M, false, GN>(in, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) {
+                div = t;
+                break;
+            }
+        }
+        first = false;
+        if (div < 0 || !a.retry) break;
+        // ilqr.py:166-169
+        dlam = fmax(dlam * a.sched.mult_lmbda, a.sched.mult_lmbda);
+        lam = fmax(lam * dlam, a.sched.min_lmbda);
+        if (!(lam <= a.sched.max_lmbda) || !(lam < 1e300) || ++retries >= kMaxLambdaRetries) break;
+    }
+    a.io.diverge[p] = div;
+    a.io.dV[p] = dV0;
+    a.io.dV[NP + p] = dV1;
+    if (a.retry) {
+        a.io.lmbda[p] = lam;
+        if (a.io.dlmbda) a.io.dlmbda[p] = dlam;
+    }
+    if constexpr (GN) {
+        if (a.io.g_norm) a.io.g_norm[p] = gmax[0];
+    }
+}
+
+template <class SYS>
+static constexpr bool fused_tpp_model() {
+    return SYS::kStatic && SYS::M == 1 && SYS::N >= 2 && SYS::N <= 4;
+}
+
+struct FusedTppLaunch {
+    FusedTppArgs a;
+    bool gn, done;
+    hipStream_t st;
+    template <class SYS>
+    void operator()() {
+        if constexpr (fused_tpp_model<SYS>()) {
+            const dim3 grid((unsigned)((a.t.NP + 63) / 64)), block(64);
+            if (gn) hipLaunchKernelGGL((fused_tpp_kernel<SYS, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((fused_tpp_kernel<SYS, false>), grid, block, 0, st, a);
+            done = true;
+        }
+    }
+};
+
+// Shapes / sizes the lane-per-problem fused form takes: pendulum, cartpole (identity cost features), batches large
+// enough to give most SIMDs a wave (below that the two HBM-bound launches, or fused_qb4.hip, are faster), 32-bit
+// offsets inside a slice and inside the write-through arrays.
+constexpr int64_t kFusedTppMinProblems = 32768;
+bool fused_tpp_supported(const trajopt_env_t* env, int T, int64_t NP) {
+    if (env->model != TRAJOPT_ENV_PENDULUM && env->model != TRAJOPT_ENV_CARTPOLE) return false;
+    if (env->nb_features != 0 || NP < kFusedTppMinProblems) return false;
+    const int n = env->dm_state;
+    return (double)TRAJOPT_GAIN_BANKS * n * n * (double)NP * 8.0 + 512.0 < 4294967296.0 &&
+           (double)n * (T + 1) * (double)NP * 8.0 < 4294967296.0 - 1024.0;
+}
+
+// io: as for trajopt_ilqr_backward_pass_batched with the structured cost set and gains-only outputs; A, B, cx, cu are
+// not used (nor written).
+int launch_fused_tpp(const trajopt_env_t* env, const trajopt_backward_io_t& io, int reg, int T, int64_t NP, int retry,
+                     const trajopt_lambda_schedule_t& sched, const double* xref, const double* uref, const RefView* rv,
+                     hipStream_t st) {
+    if (!fused_tpp_supported(env, T, NP) || !io.cost_w) return TRAJOPT_ERR_UNSUPPORTED;
+    FusedTppLaunch L;
+    L.a.t.io = io; L.a.t.sched = sched; L.a.t.NP = (size_t)NP; L.a.t.T = T; L.a.t.reg = reg; L.a.t.retry = retry; L.a.t.lpw = 64;
+    L.a.env = *env; L.a.xref = xref; L.a.uref = uref;
+    L.a.rv = rv ? *rv : RefView{nullptr, nullptr, nullptr, nullptr, nullptr};
+    L.gn = io.uref != nullptr && io.g_norm != nullptr; L.done = false; L.st = st;
+    if (!dispatch_model(*env, L) || !L.done) return TRAJOPT_ERR_UNSUPPORTED;
+    TRAJOPT_HIP_CHECK(hipGetLastError());
+    return TRAJOPT_OK;
 }
 
 

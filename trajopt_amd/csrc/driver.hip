@@ -25,6 +25,10 @@ int launch_quadratize(const trajopt_env_t* env, int T, int64_t NP, int layout, i
                       const RefView* rv, int out_layout);
 
 bool fused_qb4_supported(const trajopt_env_t* env, int T, int64_t NP);
+bool fused_tpp_supported(const trajopt_env_t* env, int T, int64_t NP);
+int launch_fused_tpp(const trajopt_env_t* env, const trajopt_backward_io_t& io, int reg, int T, int64_t NP, int retry,
+                     const trajopt_lambda_schedule_t& sched, const double* xref, const double* uref, const RefView* rv,
+                     hipStream_t st);
 bool rollout_straight_line(int n, int m, size_t NP, int nb_alphas);
 int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want);
 int launch_fused_qb4(const trajopt_env_t* env, const trajopt_backward_io_t& io, int reg, int T, int64_t NP, int retry,
@@ -390,11 +394,13 @@ int trajopt_ilqr_plan(const trajopt_env_t* env, const trajopt_ilqr_options_t* op
     const int64_t NP = ws->nb_problems;
     const bool gminor = GL == TRAJOPT_LAYOUT_PROBLEM_MINOR;
     plan->structured_cost = env->nb_features == 0 && trajopt_backward_supports_structured_cost(n, m, T, NP, GL) != 0;
-    plan->fused_quad_bwd = plan->structured_cost && gminor && !opt->keep_value && !opt->no_fusion && fused_qb4_supported(env, T, NP);
+    const bool may_fuse = plan->structured_cost && gminor && !opt->keep_value && !opt->no_fusion;
+    plan->fused_quad_bwd = may_fuse && fused_qb4_supported(env, T, NP) ? 1 : (may_fuse && fused_tpp_supported(env, T, NP) ? 2 : 0);
     bool staged = opt->staged_line_search == 1 || (opt->staged_line_search < 0 && (int64_t)NP * opt->nb_alphas >= 16 * 65536);
     if (opt->argmin_alpha || opt->nb_alphas < 2 || !ws->pending_list || !ws->pending_count) staged = false;
     plan->staged_line_search = staged;
-    plan->backward_kernel = plan->fused_quad_bwd ? TRAJOPT_KERNEL_MFMA4 : backward_kernel_family(n, m, T, NP, GL, TRAJOPT_KERNEL_AUTO);
+    plan->backward_kernel = plan->fused_quad_bwd == 1 ? TRAJOPT_KERNEL_MFMA4 : plan->fused_quad_bwd == 2 ? TRAJOPT_KERNEL_LANE
+                                                      : backward_kernel_family(n, m, T, NP, GL, TRAJOPT_KERNEL_AUTO);
     // (the fast rollout variant at all: built-in model, plain cost - rollout.hip)
     const bool fast = env->model != TRAJOPT_ENV_LQR && !env->slew_rate && env->periodic == 0 && !env->cost_times_dt && env->nb_features == 0;
     plan->rollout_straight_line = fast && !staged && rollout_straight_line(n, m, (size_t)NP, opt->nb_alphas);
@@ -434,7 +440,9 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         for (int i = 0; i < n; ++i) io.cost_gxx[i] = sc * 2.0 * env->gw[i];
         for (int j = 0; j < m; ++j) io.cost_guu[j] = sc * 2.0 * env->uw[j];
     }
-    const bool fused_qb = structured && gminor && !opt->keep_value && !opt->no_fusion && fused_qb4_supported(env, T, NP);
+    const bool may_fuse = structured && gminor && !opt->keep_value && !opt->no_fusion;
+    const bool fused_qb = may_fuse && fused_qb4_supported(env, T, NP);
+    const bool fused_lane = may_fuse && !fused_qb && fused_tpp_supported(env, T, NP);
     // staged line search: worth its second 500-step latency chain, and the scattered accesses of its compacted second
     // stage, only once the one-launch form oversubscribes the chip (1024 SIMDs x 64 lanes) many times over - measured
     // on 65 536 cartpoles x 11 alphas early in an optimisation (most problems reject alphas[0]): one launch 8.6 ms,
@@ -460,6 +468,11 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
             // handed over through LDS (fused_qb4.hip); reported under the "backward" phase
             prof_mark(st, slot, 2);
             rc = launch_fused_qb4(env, io, opt->reg, T, NP, 1, opt->sched, ws->xref, ws->uref, &rv, st);
+            if (rc != TRAJOPT_OK) return rc;
+        } else if (fused_lane) {
+            // large batches of the same models: lane = problem, the expansion in registers (bwd_tpp.hip)
+            prof_mark(st, slot, 2);
+            rc = launch_fused_tpp(env, io, opt->reg, T, NP, 1, opt->sched, ws->xref, ws->uref, &rv, st);
             if (rc != TRAJOPT_OK) return rc;
         } else {
             rc = launch_quadratize(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 0, ws->xref, ws->uref, ws->weighting,
