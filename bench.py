@@ -250,14 +250,18 @@ def main():
         census = stamped("r02_rollout_isa_census.json", stamp)
         traffic = pmc["by_phase"].get(dom) if pmc else None
         hbm_alg = ab[dom] * N * T / (dom_ms * 1e-3) / 1e9
-        if dom == "rollout" and census and a.env in census["kernels"] and plan["rollout_straight_line"]:
+        if dom == "rollout" and census and a.env in census["kernels"]:
             # the rollout is a chain of plain fp64 vector instructions: priced against the fp64 VALU peak, with the
             # flops of one step counted in the kernel's ISA (profiles/r02_rollout_isa_census.json)
             fl = census["kernels"][a.env]["fp64_flops_per_lane_step"]
             achieved = fl * N * nb_alphas * T / (dom_ms * 1e-3) / 1e12
             roof = {"bound": "fp64-valu", "kernel": dom, "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
-                    "fp64_flops_per_lane_step": fl, "instructions_per_step": census["kernels"][a.env]["instructions_per_step"],
+                    "fp64_flops_per_lane_step": fl,
+                    # counted in the straight-line form's block loop; the rolled form (oversubscribed batches) runs the
+                    # same fp64 arithmetic per step around different loop / addressing code
+                    "instructions_per_step": census["kernels"][a.env]["instructions_per_step"] if plan["rollout_straight_line"] else None,
+                    "flops_counted_on": "this kernel" if plan["rollout_straight_line"] else "the straight-line form of the same model (same arithmetic per step)",
                     "lanes": N * nb_alphas, "waves_per_simd": N * nb_alphas / 64.0 / 1024.0,
                     "hbm_algorithmic_GBps": hbm_alg, "hbm_frac": hbm_alg / HBM_PEAK_GBS,
                     "alg_bytes_per_launch": ab[dom] * N * T, "avg_launch_ms": dom_ms,
