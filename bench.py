@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--instances", type=int, default=4096, help="problems per GPU (C2: 4096)")
     ap.add_argument("--horizon", type=int, default=500)
     ap.add_argument("--env", default="cartpole")
-    ap.add_argument("--staged", type=int, default=-1, help="line search: -1 auto, 0 one launch, 1 staged (same results)")
+    ap.add_argument("--staged", type=int, default=-1, help="line search: -1 auto, 0 one launch, 1 staged, 2 returns first then the accepted alpha again (same results)")
     ap.add_argument("--no-fusion", action="store_true", help="quadratise and backward pass as two launches (same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -254,7 +254,10 @@ def main():
             # the rollout is a chain of plain fp64 vector instructions: priced against the fp64 VALU peak, with the
             # flops of one step counted in the kernel's ISA (profiles/r02_rollout_isa_census.json)
             fl = census["kernels"][a.env]["fp64_flops_per_lane_step"]
-            achieved = fl * N * nb_alphas * T / (dom_ms * 1e-3) / 1e12
+            # two-pass line search (plan 2): every (problem, alpha) once for its return, the accepted alpha of each problem
+            # once more for its trajectory - the phase holds both launches and the select kernel between them
+            lanes = N * nb_alphas + (N if plan["staged_line_search"] == 2 else 0)
+            achieved = fl * lanes * T / (dom_ms * 1e-3) / 1e12
             roof = {"bound": "fp64-valu", "kernel": dom, "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
                     "fp64_flops_per_lane_step": fl,
@@ -262,7 +265,8 @@ def main():
                     # same fp64 arithmetic per step around different loop / addressing code
                     "instructions_per_step": census["kernels"][a.env]["instructions_per_step"] if plan["rollout_straight_line"] else None,
                     "flops_counted_on": "this kernel" if plan["rollout_straight_line"] else "the straight-line form of the same model (same arithmetic per step)",
-                    "lanes": N * nb_alphas, "waves_per_simd": N * nb_alphas / 64.0 / 1024.0,
+                    "lanes": lanes, "waves_per_simd": lanes / 64.0 / 1024.0,
+                    "launches": "returns of every alpha, select, the accepted alpha again" if plan["staged_line_search"] == 2 else "one",
                     "hbm_algorithmic_GBps": hbm_alg, "hbm_frac": hbm_alg / HBM_PEAK_GBS,
                     "alg_bytes_per_launch": ab[dom] * N * T, "avg_launch_ms": dom_ms,
                     "valu_insts_per_simd_cycle_pmc": (sq["kernels_by_phase"].get(dom, {}).get("valu_insts_per_simd_cycle") if sq else None)}

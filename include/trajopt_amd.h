@@ -373,6 +373,9 @@ typedef struct trajopt_ilqr_options {
      *   1 = staged like the reference's sequential loop (ilqr.py:187-202): alphas[0] for everybody, then the
      *       remaining alphas only for the problems that rejected it, compacted so that waves stay full (needs
      *       ws->pending_list / ws->pending_count; ignored with argmin_alpha);
+     *   2 = two passes: the returns of every (problem, alpha) without writing any trajectory, then the accepted alpha
+     *       of each problem rolled out once more and written (large batches, where the stores of the candidates nobody
+     *       reads dominate; built-in models with the plain cost, otherwise 0 is taken);
      *  -1 = pick by batch size. */
     int32_t staged_line_search;
     /* 1 = never fuse the quadratisation into the backward kernel (fused_qb4.hip): always the two launches
@@ -452,7 +455,8 @@ typedef struct trajopt_ilqr_plan {
     int32_t structured_cost;   /* 1: closed-form Cxx / Cuu / Cxu formed inside the backward kernel (cost_w)            */
     int32_t fused_quad_bwd;    /* quadratisation and backward pass in one launch: 1 = four problems per wave (fused_qb4.hip,
                                   small batches), 2 = lane per problem (bwd_tpp.hip, >= 32768 problems); 0 = two launches */
-    int32_t staged_line_search;/* 1: alphas[0] for everybody, the rest for the compacted list of rejecting problems   */
+    int32_t staged_line_search;/* 0 one launch; 1: alphas[0] for everybody, the rest for the compacted list of rejecting
+                                  problems; 2: returns of every alpha first, then the accepted one again, written     */
     int32_t backward_kernel;   /* TRAJOPT_KERNEL_* family of the backward pass                                         */
     int32_t rollout_straight_line; /* 1: the rollout's lone-wave form (8 steps of straight-line code per block)        */
     int32_t pad_;

@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from trajopt_amd import _lib  # noqa: E402
 
-KERNELS = {"cartpole": "rollout_kernelINS_7SysPhysILi2EEELb1ELb1ELb1ELb1ELb1EEEvNS_11RolloutArgsE",
-           "pendulum": "rollout_kernelINS_7SysPhysILi1EEELb1ELb1ELb1ELb1ELb1EEEvNS_11RolloutArgsE"}
+KERNELS = {"cartpole": "rollout_kernelINS_7SysPhysILi2EEELb1ELb1ELb1ELb1ELb1ELb0EEEvNS_11RolloutArgsE",
+           "pendulum": "rollout_kernelINS_7SysPhysILi1EEELb1ELb1ELb1ELb1ELb1ELb0EEEvNS_11RolloutArgsE"}
 
 
 def main():

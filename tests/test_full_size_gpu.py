@@ -289,3 +289,58 @@ def test_lane_fused_quadratise_backward_at_32768_problems(oracle, name, kw):
         assert_close(a["xref"][p], r["xref"], "xref", tol=1e-8)
         if len(r["trace"]) > 1:
             assert_close(a["K"][p], r["K"], "K", tol=1e-8)
+
+
+@pytest.mark.parametrize("argmin,keep_value", [(False, False), (True, False), (False, True)])
+def test_two_pass_line_search_at_16384_problems(oracle, argmin, keep_value):
+    """Large batches of small models take the line search in two passes (plan staged_line_search = 2, rollout.hip: the
+    returns of every (problem, alpha) without writing a trajectory, then the accepted alpha of each problem rolled out
+    again and written): scheduling only - every output must be bitwise what the one-launch line search gives (ilqr.py:
+    187-231), on a batch that mixes problems accepting different alphas with problems rejecting all of them; a sample
+    against the oracle's driver."""
+    from tests.test_ilqr_gpu import _pair
+    from trajopt_amd.ilqr import BatchedILQR
+    pe, oe = _pair("cartpole", dt=0.02, uw=[1e-5])
+    N, T = 16384, 24
+    rng = np.random.Generator(np.random.PCG64(12))
+    x0 = np.asarray(pe.x0)[None] + 0.3 * rng.standard_normal((N, pe.dm_state))
+    kff0 = 1e-2 * rng.standard_normal((N, pe.dm_act, T))
+    keys = ("xref", "uref", "K", "kff", "lmbda", "dlmbda", "status", "iters", "last_return", "alpha") + (("V", "v", "Quu") if keep_value else ())
+    runs = {}
+    for mode in (-1, 0):
+        s = BatchedILQR(pe, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False, staged_line_search=mode,
+                        argmin_alpha=argmin, keep_value=keep_value)
+        assert s.plan()["staged_line_search"] == (2 if mode < 0 else 0)
+        s.run(nb_iter=2)                    # two iterations chained in one call ...
+        s.iterate(1)                        # ... and single ones
+        traces = s.run(nb_iter=1)
+        runs[mode] = dict(traces=traces, **{k: s.host(k) for k in keys})
+    a, b = runs[-1], runs[0]
+    assert a["traces"] == b["traces"]
+    for k in keys:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert len(np.unique(a["alpha"][~np.isnan(a["alpha"])])) > 1, "the batch must accept different step sizes"
+    assert len({len(t) for t in a["traces"]}) > 1, "the batch must mix accepting and rejecting problems"
+    if not argmin and not keep_value:
+        for p in list(range(0, N, 2731)) + [N - 1]:
+            r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=4)
+            assert a["status"][p] == r["status"] and a["iters"][p] == r["iters"]
+            assert abs(a["last_return"][p] - r["last_return"]) <= TOL * abs(r["last_return"])
+            assert_close(a["xref"][p], r["xref"], "xref", tol=1e-8)
+
+
+def test_two_pass_line_search_falls_back_where_there_is_no_returns_only_rollout():
+    """Asked for explicitly on an env the returns-only rollout is not built for (slew-rate cost, wrapped angle), or
+    with a single alpha, the plan says one launch - and the solver runs."""
+    from trajopt_amd import envs
+    from trajopt_amd.ilqr import BatchedILQR
+    rng = np.random.Generator(np.random.PCG64(13))
+    N, T = 256, 16
+    for name, kw, extra in (("pendulum", dict(dt=0.05, slew_rate=True, periodic=True), {}),
+                            ("cartpole", dict(dt=0.02), dict(alphas=np.array([1.0])))):
+        env = envs.make(name, **kw)
+        x0 = np.asarray(env.x0)[None] + 0.1 * rng.standard_normal((N, env.dm_state))
+        s = BatchedILQR(env, T, x0, staged_line_search=2, **extra)
+        assert s.plan()["staged_line_search"] == 0
+        s.run(nb_iter=2)
+        assert np.all(np.isfinite(s.host("last_return")))

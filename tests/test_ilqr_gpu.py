@@ -352,8 +352,9 @@ def test_batched_mpc_matches_the_reference_loop(oracle):
 @pytest.mark.parametrize("name,kw", [("cartpole", dict(dt=0.02)), ("pendulum", dict(dt=0.05))])
 def test_staged_line_search_is_bitwise_the_one_launch_line_search(oracle, name, kw):
     """Scheduling only: alphas[0] for everybody, the rest for the compacted list of rejecting problems
-    (the reference's sequential first-accept loop, ilqr.py:187-202) must give the same numbers as rolling every
-    alpha out at once."""
+    (the reference's sequential first-accept loop, ilqr.py:187-202), and the two-pass form (returns of every alpha
+    first, the accepted one rolled out again and written) must give the same numbers as rolling every alpha out at
+    once."""
     from trajopt_amd import envs
     from trajopt_amd.ilqr import BatchedILQR
     rng = np.random.default_rng(21)
@@ -362,13 +363,14 @@ def test_staged_line_search_is_bitwise_the_one_launch_line_search(oracle, name, 
     x0 = np.asarray(env0.x0)[None] + 0.3 * rng.standard_normal((N, env0.dm_state))
     kff0 = 1e-4 * rng.standard_normal((N, env0.dm_act, T))
     res = []
-    for staged in (0, 1):
+    for staged in (0, 1, 2):
         env = envs.make(name, **kw)
         s = BatchedILQR(env, T, x0, kff_init=kff0, action_penalty=1e-5, staged_line_search=staged)
+        assert s.plan()["staged_line_search"] == staged
         used = []
         s.init_rollout()
-        for _ in range(6):
-            s.iterate(1)
+        for k in (1, 1, 3, 1):   # (3: iterations chained inside one call)
+            s.iterate(k)
             used.append(s.host("alpha").copy())
         res.append({k: s.host(k).copy() for k in ("xref", "uref", "K", "kff", "last_return", "lmbda", "alpha", "status")})
         res[-1]["alphas_used"] = np.stack(used)
@@ -376,6 +378,7 @@ def test_staged_line_search_is_bitwise_the_one_launch_line_search(oracle, name, 
         assert len(np.unique(res[0]["alphas_used"])) > 1, "the case must exercise alphas beyond the first"
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k], equal_nan=True), k
+        assert np.array_equal(res[0][k], res[2][k], equal_nan=True), k
     oe = oracle.make_env(name, dt=kw["dt"], uw=[1e-5])
     for p in range(0, N, 37):
         r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=6)

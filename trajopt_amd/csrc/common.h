@@ -72,6 +72,10 @@ struct RefView {
 struct RolloutPlanes {
     int first_plane, junk_plane;
     const int32_t* out_bank;   // bank of the multi-buffered gains each problem reads (NULL: plain K / kff)
+    // Two-pass line search (driver.hip): pass 1 = cost_only (returns of every alpha, no trajectory written); pass 2 =
+    // sel given: one lane per problem rolls alpha sel[p] (>= 0) out again and writes it to plane first_plane + sel[p]
+    int cost_only;
+    const int32_t* sel;
 };
 
 // Bank of the multi-buffered gains problem p writes (trajopt_backward_io_t::out_bank), 0 without banks.

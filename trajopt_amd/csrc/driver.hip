@@ -30,6 +30,7 @@ int launch_fused_tpp(const trajopt_env_t* env, const trajopt_backward_io_t& io, 
                      const trajopt_lambda_schedule_t& sched, const double* xref, const double* uref, const RefView* rv,
                      hipStream_t st);
 bool rollout_straight_line(int n, int m, size_t NP, int nb_alphas);
+bool rollout_cost_only_supported(const trajopt_env_t* env, int T, int64_t NP, int k_layout);
 int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want);
 int launch_fused_qb4(const trajopt_env_t* env, const trajopt_backward_io_t& io, int reg, int T, int64_t NP, int retry,
                      const trajopt_lambda_schedule_t& sched, const double* xref, const double* uref,
@@ -385,6 +386,31 @@ int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_optio
     return TRAJOPT_OK;
 }
 
+// How an iteration evaluates its step sizes (trajopt_ilqr_options_t::staged_line_search; reported by trajopt_ilqr_plan):
+//   0  one launch: every (problem, alpha) rolls out and writes its candidate trajectory;
+//   1  staged: alphas[0] for everybody, the remaining ones only for the problems that rejected it - worth its second
+//      500-step latency chain, and the scattered accesses of its compacted second stage, only once the one-launch form
+//      oversubscribes the chip (1024 SIMDs x 64 lanes) many times over - measured on 65 536 cartpoles x 11 alphas early in
+//      an optimisation (most problems reject alphas[0]): one launch 8.6 ms, staged 12.6 ms; never with argmin (needs
+//      every alpha) or a single alpha;
+//   2  two passes: the returns of every (problem, alpha) without writing a trajectory, then the accepted step size of
+//      each problem once more, written.  The stores of the nb_alphas - 1 candidates nobody reads are most of what a
+//      large rollout moves (65 536 cartpoles: 14.4 GB of 18.3 per launch); the price is a second latency chain of one
+//      lane per problem, so it is taken from 2.5 waves per SIMD on (small models; 6 for the others).
+static int line_search_mode(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt, const trajopt_ilqr_workspace_t* ws) {
+    const int64_t lanes = ws->nb_problems * (int64_t)opt->nb_alphas;
+    const bool can_stage = !opt->argmin_alpha && opt->nb_alphas >= 2 && ws->pending_list && ws->pending_count;
+    const bool can_two = opt->nb_alphas >= 2 && rollout_cost_only_supported(env, ws->nb_steps, ws->nb_problems, ws->gains_layout);
+    if (opt->staged_line_search == 1) return can_stage ? 1 : 0;
+    if (opt->staged_line_search == 2) return can_two ? 2 : 0;
+    if (opt->staged_line_search == 0) return 0;
+    if (can_stage && lanes >= 16 * 65536) return 1;
+    // (measured, 11 alphas, T = 500: cartpoles win from 16 384 problems on - 3.34 -> 2.76 ms an iteration - and would from
+    // ~10 000; double cartpoles, whose second chain is 0.9 ms, lose at 16 384 - 5.90 -> 6.21 - and win 5 % at 32 768)
+    if (can_two && lanes >= (env->dm_state + env->dm_act <= 5 ? 5 * 32768 : 6 * 65536)) return 2;
+    return 0;
+}
+
 int trajopt_ilqr_plan(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt, const trajopt_ilqr_workspace_t* ws,
                       trajopt_ilqr_plan_t* plan) {
     if (!plan) return TRAJOPT_ERR_BAD_ARG;
@@ -396,14 +422,14 @@ int trajopt_ilqr_plan(const trajopt_env_t* env, const trajopt_ilqr_options_t* op
     plan->structured_cost = env->nb_features == 0 && trajopt_backward_supports_structured_cost(n, m, T, NP, GL) != 0;
     const bool may_fuse = plan->structured_cost && gminor && !opt->keep_value && !opt->no_fusion;
     plan->fused_quad_bwd = may_fuse && fused_qb4_supported(env, T, NP) ? 1 : (may_fuse && fused_tpp_supported(env, T, NP) ? 2 : 0);
-    bool staged = opt->staged_line_search == 1 || (opt->staged_line_search < 0 && (int64_t)NP * opt->nb_alphas >= 16 * 65536);
-    if (opt->argmin_alpha || opt->nb_alphas < 2 || !ws->pending_list || !ws->pending_count) staged = false;
-    plan->staged_line_search = staged;
+    const int ls = line_search_mode(env, opt, ws);
+    const bool staged = ls == 1;
+    plan->staged_line_search = ls;
     plan->backward_kernel = plan->fused_quad_bwd == 1 ? TRAJOPT_KERNEL_MFMA4 : plan->fused_quad_bwd == 2 ? TRAJOPT_KERNEL_LANE
                                                       : backward_kernel_family(n, m, T, NP, GL, TRAJOPT_KERNEL_AUTO);
     // (the fast rollout variant at all: built-in model, plain cost - rollout.hip)
     const bool fast = env->model != TRAJOPT_ENV_LQR && !env->slew_rate && env->periodic == 0 && !env->cost_times_dt && env->nb_features == 0;
-    plan->rollout_straight_line = fast && !staged && rollout_straight_line(n, m, (size_t)NP, opt->nb_alphas);
+    plan->rollout_straight_line = fast && ls == 0 && rollout_straight_line(n, m, (size_t)NP, opt->nb_alphas);
     plan->pad_ = 0;
     return TRAJOPT_OK;
 }
@@ -443,13 +469,8 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
     const bool may_fuse = structured && gminor && !opt->keep_value && !opt->no_fusion;
     const bool fused_qb = may_fuse && fused_qb4_supported(env, T, NP);
     const bool fused_lane = may_fuse && !fused_qb && fused_tpp_supported(env, T, NP);
-    // staged line search: worth its second 500-step latency chain, and the scattered accesses of its compacted second
-    // stage, only once the one-launch form oversubscribes the chip (1024 SIMDs x 64 lanes) many times over - measured
-    // on 65 536 cartpoles x 11 alphas early in an optimisation (most problems reject alphas[0]): one launch 8.6 ms,
-    // staged 12.6 ms; never with argmin (needs every alpha) or a single alpha
-    bool staged = opt->staged_line_search == 1 ||
-                  (opt->staged_line_search < 0 && (int64_t)NP * opt->nb_alphas >= 16 * 65536);
-    if (opt->argmin_alpha || opt->nb_alphas < 2 || !ws->pending_list || !ws->pending_count) staged = false;
+    const int ls = line_search_mode(env, opt, ws);
+    const bool staged = ls == 1, two_pass = ls == 2;
     // No copy on accept: the quadratisation reads the reference through ref_plane (time-blocked planes: whole 64-byte
     // runs per problem, whatever planes its neighbours read) and writes what it read through to the dense xref / uref,
     // where the backward kernels' gradient norm and the rollout find it; iteration `it` of this call writes its
@@ -487,7 +508,15 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         prof_mark(st, slot, 3);
         hipLaunchKernelGGL(post_backward_kernel, dim3(g1), dim3(256), 0, st, a, wb);
         prof_mark(st, slot, 4);
-        if (!staged) {
+        if (two_pass) {
+            // pass 1: the returns of every (problem, alpha), nothing else written
+            const RolloutPlanes rp1{rp.first_plane, rp.junk_plane, rp.out_bank, 1, nullptr};
+            rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
+                                ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
+                                ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 0, opt->nb_alphas,
+                                nullptr, nullptr, &rp1);
+            if (rc != TRAJOPT_OK) return rc;
+        } else if (!staged) {
             rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
                                 ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                                 ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 0, opt->nb_alphas,
@@ -507,8 +536,22 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
                                 ws->pending_list, ws->pending_count, &rp);
             if (rc != TRAJOPT_OK) return rc;
         }
-        prof_mark(st, slot, 5);
-        hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a, it + 1 < nb_iter ? 1 : 0, staged ? 1 : 0, wb);
+        if (!two_pass) prof_mark(st, slot, 5);
+        hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a, (it + 1 < nb_iter && !two_pass) ? 1 : 0, staged ? 1 : 0, wb);
+        if (two_pass) {
+            // pass 2: the accepted step size of every problem once more (same arithmetic, same results), this time
+            // written to its plane, which select_kernel has just made the reference; it reads the gains through
+            // out_bank, so the next iteration's prep (which moves out_bank on) follows it instead of riding in select.
+            // Reported under the "rollout" phase.
+            const RolloutPlanes rp2{rp.first_plane, rp.junk_plane, rp.out_bank, 0, ws->sel};
+            rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
+                                ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, nullptr, ws->cand_state,
+                                ws->cand_action, nullptr, nullptr, nullptr, st, GL, 0, opt->nb_alphas, nullptr, nullptr,
+                                &rp2);
+            if (rc != TRAJOPT_OK) return rc;
+            prof_mark(st, slot, 5);
+            if (it + 1 < nb_iter) hipLaunchKernelGGL(prep_kernel, dim3(g1), dim3(256), 0, st, a, wb ^ 1);
+        }
         if (opt->keep_value) {
             if (gminor) hipLaunchKernelGGL(promote_value_kernel<true>, g2, dim3(256), 0, st, a);
             else hipLaunchKernelGGL(promote_value_kernel<false>, g2, dim3(256), 0, st, a);

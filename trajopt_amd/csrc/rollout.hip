@@ -35,6 +35,9 @@ struct RolloutArgs {
     // ... and the gains K / kff hold TRAJOPT_GAIN_BANKS banks, of which problem p reads bank out_bank[p] (layout:
     // trajopt_backward_io_t::out_bank); NULL: plain arrays
     const int32_t* out_bank;
+    // Second pass of the driver's two-pass line search: ONE lane per problem, which rolls out alpha sel[p] again (the
+    // step size select_kernel accepted; < 0: nothing to do) and writes its trajectory; NULL: every (problem, alpha)
+    const int32_t* sel;
 };
 
 // index into the gains K / kff, which hold kmul banks when the driver multi-buffers them
@@ -100,7 +103,10 @@ __device__ __forceinline__ void tb_flush(const TbStage<ROWS>& sg, const unsigned
 // UNR (with FAST and TB): the 8 steps of a block are straight-line code.  That is the fastest form for a lone wave per
 // SIMD (no wait at all for a block's write-out), but it takes 256 registers and more, i.e. one wave per SIMD; batches
 // that oversubscribe the chip take the rolled form (two waves per SIMD hide its one wait per block).
-template <class SYS, bool MINOR, bool KMINOR, bool FAST, bool TB, bool UNR>
+// CO (with FAST, without TB): returns only, no trajectory is written - the first pass of the two-pass line search.
+// (The returns-only cartpole takes 176 registers, 2 waves per SIMD; held to 168 for 3 - __launch_bounds__(64, 3), 36
+// bytes of spills - 65 536 cartpoles took 8.4 instead of 7.8 ms an iteration, 16 384 2.98 instead of 2.76.)
+template <class SYS, bool MINOR, bool KMINOR, bool FAST, bool TB, bool UNR, bool CO = false>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     constexpr int N = SYS::N, M = SYS::M;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,7 +115,13 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     size_t p;
     int ai;
     bool idle = false;  // no early return before the barrier below
-    if (a.xcd_tiles) {
+    if (a.sel) {
+        idle = idx >= NP;
+        p = idle ? 0 : idx;
+        const int s = idle ? -1 : a.sel[p];
+        idle = s < 0;
+        ai = idle ? a.alpha_begin : s;
+    } else if (a.xcd_tiles) {
         // The driver's order: the nA step sizes of a tile of 64 problems are consecutive workgroups OF ONE XCD
         // (workgroups b and b + 8 share one, cdna guide): they run at about the same time and read the tile's gains
         // and reference through one L2, where the plain order - alpha slowest - fetches them from HBM once per alpha.
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
             x[i] = a.x0[gi<MINOR>(i, n, p, NP)];
             fin = fin && (x[i] < 1e8);
             if constexpr (TB) put_x(0, i, x[i]);
-            else if (FAST || a.state) st[gi<MINOR>(i, En1, p, NP)] = x[i];
+            else if constexpr (!CO) { if (FAST || a.state) st[gi<MINOR>(i, En1, p, NP)] = x[i]; }
         }
     if constexpr (FAST) {
         // The driver's variant.  Addresses are a wave-uniform slice pointer per array (advanced with scalar adds) plus
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         };
         double* sp[N];
         double* ap[M];
-        if constexpr (!TB) {
+        if constexpr (!TB && !CO) {
 #pragma unroll
             for (int i = 0; i < N; ++i) sp[i] = st + ((size_t)i * NP + p);
 #pragma unroll
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         // seen to have arrived once those 40 stores have been acknowledged.
         // (kAhead2: for the lone-wave forms.  Where several waves share a SIMD they hide that wait for each other, and
         // the plain one-step-ahead prefetch into the other register set needs fewer registers - an occupancy step for dx = 6.)
-        constexpr bool kAhead2 = !TB || UNR;
+        constexpr bool kAhead2 = (!TB || UNR) && !CO;
         // (kOne: models with more than 8 rows a step - two register sets of their inputs (quadrotor: 68 doubles each)
         // do not fit next to the dynamics; ONE set, refilled in place with the next step's inputs as soon as the control
         // law has consumed it - they arrive while the dynamics integrate.)
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 if constexpr (TB) put_u(t, j, u[j]);
-                else { *ap[j] = u[j]; ap[j] += dsu; }
+                else if constexpr (!CO) { *ap[j] = u[j]; ap[j] += dsu; }
             }
             double xn[N];
             SYS::dynamics_clipped(e, x, u, xn);
@@ -316,7 +328,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 x[i] = xn[i];
                 fin = fin && (x[i] < 1e8);
                 if constexpr (TB) { if constexpr (put_next) put_x(t + 1, i, x[i]); }
-                else { sp[i] += dsx; *sp[i] = x[i]; }
+                else if constexpr (!CO) { sp[i] += dsx; *sp[i] = x[i]; }
             }
         };
         In sa, sb;
@@ -501,28 +513,45 @@ bool rollout_straight_line(int n, int m, size_t NP, int nb_alphas) {
     return (double)NP * nb_alphas <= 64.0 * 1024.0 && n + m <= 7;
 }
 
+// The returns-only form (CO) exists for the variant the driver's plain-cost call takes (FAST in rollout_kernel).
+bool rollout_cost_only_supported(const trajopt_env_t* env, int T, int64_t NP, int k_layout) {
+    if (env->model == TRAJOPT_ENV_LQR || env->slew_rate || env->periodic != 0 || env->cost_times_dt || env->nb_features != 0 || T <= 0)
+        return false;
+    const double nm = (double)env->dm_state * env->dm_act;
+    const double kbytes = (double)TRAJOPT_GAIN_BANKS * (k_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR ? nm * (double)NP * 8.0 : (double)NP * nm * (double)T * 8.0);
+    return kbytes + (double)NP * 8.0 < 4294967296.0;
+}
+
 struct RolloutLaunch {
     RolloutArgs a;
     bool tb;   // time-blocked candidate planes (the driver's call)
+    bool cost_only;   // no trajectories (CO)
+    int err = TRAJOPT_OK;
     int layout, k_layout;
     hipStream_t st;
     template <class SYS>
     void operator()() {
-        const size_t total = a.NP * (size_t)(a.nb_alphas - a.alpha_begin);
+        const size_t nA = a.sel ? 1 : (size_t)(a.nb_alphas - a.alpha_begin);
+        const size_t total = a.NP * nA;
         const size_t tiles8 = (a.NP + 511) / 512;   // tiles of 64 problems, rounded up to a multiple of 8 (one per XCD)
-        const dim3 grid((unsigned)(a.xcd_tiles ? tiles8 * 8 * (size_t)(a.nb_alphas - a.alpha_begin) : (total + 63) / 64)), block(64);
+        const dim3 grid((unsigned)(a.xcd_tiles ? tiles8 * 8 * nA : (total + 63) / 64)), block(64);
         const bool mi = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR, kmi = k_layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
         // (FAST addresses the gains with 32-bit per-lane byte offsets)
         const double kbytes = (a.out_bank ? (double)TRAJOPT_GAIN_BANKS : 1.0) * (kmi ? (double)SYS::N * SYS::M * (double)a.NP * 8.0
                                                                                      : (double)a.NP * SYS::N * SYS::M * (double)a.T * 8.0);
-        const bool fast = SYS::kStatic && a.state && a.action && !a.cost && !a.env.slew_rate && a.env.periodic == 0 &&
+        const bool fast = SYS::kStatic && (cost_only || (a.state && a.action)) && !a.cost && !a.env.slew_rate && a.env.periodic == 0 &&
                           !a.env.cost_times_dt && a.env.nb_features == 0 && a.T > 0 && kbytes + (double)a.NP * 8.0 < 4294967296.0;
         if constexpr (SYS::kStatic) {
+            if (mi && fast && cost_only) {
+                if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, false, false, true>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, false, false, true>), grid, block, 0, st, a);
+                return;
+            }
             if (mi && fast) {
                 // straight-line blocks while every wave has a SIMD to itself (and the model's registers allow it)
                 // (tried for dx + du >= 6, where the stage's LDS allows one wave per SIMD anyway: 8192 double cartpoles
                 // 1.90 ms against 1.81 rolled)
-                const bool unr = rollout_straight_line(SYS::N, SYS::M, a.NP, a.nb_alphas - a.alpha_begin);
+                const bool unr = rollout_straight_line(SYS::N, SYS::M, a.NP, (int)nA);
                 if (tb && unr && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, true, true>), grid, block, 0, st, a);
                 else if (tb && unr) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, true, true>), grid, block, 0, st, a);
                 else if (tb && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, true, false>), grid, block, 0, st, a);
@@ -532,6 +561,7 @@ struct RolloutLaunch {
                 return;
             }
         }
+        if (cost_only) { err = TRAJOPT_ERR_UNSUPPORTED; return; }   // (no returns-only form of the general kernel)
         if (tb && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false, true, false>), grid, block, 0, st, a);   // (tb: mi)
         else if (tb) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, false, true, false>), grid, block, 0, st, a);
         else if (mi && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, false, false, false>), grid, block, 0, st, a);
@@ -642,8 +672,11 @@ int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, cons
     L.a.first_plane = planes ? planes->first_plane : 0; L.a.junk_plane = planes ? planes->junk_plane : 0;
     L.a.out_bank = planes ? planes->out_bank : nullptr;
     // (only where the chip is oversubscribed: measured on 4096 cartpoles x 11 alphas, 704 waves, the plain order is 5 % faster)
-    L.a.xcd_tiles = (planes && (double)NP * (alpha_end - alpha_begin) > 65536.0) ? 1 : 0;
-    L.tb = planes != nullptr;
+    L.a.sel = planes ? planes->sel : nullptr;
+    L.cost_only = planes && planes->cost_only;
+    if (L.cost_only && (L.a.sel || !rollout_cost_only_supported(env, T, NP, k_layout))) return TRAJOPT_ERR_UNSUPPORTED;
+    L.a.xcd_tiles = (planes && !L.a.sel && (double)NP * (alpha_end - alpha_begin) > 65536.0) ? 1 : 0;
+    L.tb = planes != nullptr && !L.cost_only;
     nb_alphas = alpha_end;  // the kernel runs alphas [alpha_begin, alpha_end)
     L.a.env = *env;
     L.a.x0 = x0; L.a.K = K; L.a.kff = kff; L.a.xref = xref; L.a.uref = uref; L.a.weighting = weighting;
@@ -652,6 +685,7 @@ int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, cons
     L.a.NP = (size_t)NP; L.a.T = T; L.a.nb_alphas = nb_alphas;
     L.layout = layout; L.k_layout = k_layout; L.st = st;
     if (!dispatch_model(*env, L)) return TRAJOPT_ERR_UNSUPPORTED;
+    if (L.err != TRAJOPT_OK) return L.err;
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
 }

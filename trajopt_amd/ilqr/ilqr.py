@@ -150,7 +150,7 @@ class BatchedILQR:
         for i, a in enumerate(self.alphas):
             o.alphas[i] = float(a)
         o.argmin_alpha, o.keep_value = int(bool(argmin_alpha)), int(self.keep_value)
-        o.staged_line_search = int(staged_line_search)  # -1 auto, 0 one launch, 1 staged (same results)
+        o.staged_line_search = int(staged_line_search)  # -1 auto, 0 one launch, 1 staged, 2 two passes (same results)
         o.no_fusion = int(bool(no_fusion))              # True: quadratise and backward pass always as two launches
         self._opt = o
         self._ws = self._make_ws()
