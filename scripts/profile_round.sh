@@ -22,6 +22,11 @@ PYTHONPATH=. timeout -k 10 200 python scripts/bench_c1.py $O/bench_c1.json > $O/
   timeout -k 10 120 python scripts/bench_backward.py --variant riccati --n 64 --m 16 --T 1000 --N 1024 --layout 0 --reps 3 || exit 1
 } > $O/backward_all_configs.log 2>&1
 timeout -k 10 200 python bench.py --no-cpu-baseline --instances 65536 --steps 5 --warmup 2 > $O/bench_65536.json 2> $O/bench_65536.err || exit 1
+timeout -k 10 200 python bench.py --no-cpu-baseline --instances 65536 > $O/bench_65536_20steps.json 2> $O/bench_65536_20steps.err || exit 1
+# ... its issue counters and its kernel trace (two-pass line search: returns-only rollout, select, the accepted alpha again)
+timeout -s KILL 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_65536 -o k -- python bench.py --no-cpu-baseline --instances 65536 --steps 3 --warmup 2 > $O/pmc_sq_65536.log 2>&1 || exit 1
+timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_65536 -o k -- python bench.py --no-cpu-baseline --instances 65536 --steps 5 --warmup 2 > $O/kt_65536.log 2>&1 || exit 1
+for n in 16384 32768; do timeout -k 10 200 python bench.py --no-cpu-baseline --instances $n --steps 5 --warmup 2 > $O/bench_$n.json 2> $O/bench_$n.err || exit 1; done
 timeout -k 10 200 python bench.py --no-cpu-baseline --env double_cartpole --instances 8192 --steps 5 --warmup 2 > $O/bench_c3.json 2> $O/bench_c3.err || exit 1
 timeout -k 10 200 python bench.py --no-cpu-baseline --env quadrotor --instances 4096 --steps 5 --warmup 2 > $O/bench_c4.json 2> $O/bench_c4.err || exit 1
 PYTHONPATH=. timeout -k 10 200 python -u scripts/bench_gps.py $O/gps_bench.json > $O/gps_bench.log 2>&1 || exit 1

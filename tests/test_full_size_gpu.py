@@ -296,8 +296,8 @@ def test_two_pass_line_search_at_16384_problems(oracle, argmin, keep_value):
     """Large batches of small models take the line search in two passes (plan staged_line_search = 2, rollout.hip: the
     returns of every (problem, alpha) without writing a trajectory, then the accepted alpha of each problem rolled out
     again and written): scheduling only - every output must be bitwise what the one-launch line search gives (ilqr.py:
-    187-231), on a batch that mixes problems accepting different alphas with problems rejecting all of them; a sample
-    against the oracle's driver."""
+    187-231), on a batch that mixes problems accepting different alphas, problems rejecting all of them and problems
+    that stop (tolfun) at different iterations; a sample against the oracle's driver."""
     from tests.test_ilqr_gpu import _pair
     from trajopt_amd.ilqr import BatchedILQR
     pe, oe = _pair("cartpole", dt=0.02, uw=[1e-5])
@@ -309,10 +309,10 @@ def test_two_pass_line_search_at_16384_problems(oracle, argmin, keep_value):
     runs = {}
     for mode in (-1, 0):
         s = BatchedILQR(pe, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False, staged_line_search=mode,
-                        argmin_alpha=argmin, keep_value=keep_value)
+                        argmin_alpha=argmin, keep_value=keep_value, tolfun=100.0)
         assert s.plan()["staged_line_search"] == (2 if mode < 0 else 0)
-        s.run(nb_iter=2)                    # two iterations chained in one call ...
-        s.iterate(1)                        # ... and single ones
+        s.run(nb_iter=4)                    # iterations chained in one call: problems that stop early keep their
+        s.iterate(1)                        # reference in a plane the later iterations write around; and single ones
         traces = s.run(nb_iter=1)
         runs[mode] = dict(traces=traces, **{k: s.host(k) for k in keys})
     a, b = runs[-1], runs[0]
@@ -321,9 +321,10 @@ def test_two_pass_line_search_at_16384_problems(oracle, argmin, keep_value):
         assert np.array_equal(a[k], b[k], equal_nan=True), k
     assert len(np.unique(a["alpha"][~np.isnan(a["alpha"])])) > 1, "the batch must accept different step sizes"
     assert len({len(t) for t in a["traces"]}) > 1, "the batch must mix accepting and rejecting problems"
+    assert len(np.unique(a["iters"][a["status"] == 2])) > 1 and (a["status"] == 0).any(), "problems must stop at different iterations"
     if not argmin and not keep_value:
         for p in list(range(0, N, 2731)) + [N - 1]:
-            r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=4)
+            r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=6, tolfun=100.0)
             assert a["status"][p] == r["status"] and a["iters"][p] == r["iters"]
             assert abs(a["last_return"][p] - r["last_return"]) <= TOL * abs(r["last_return"])
             assert_close(a["xref"][p], r["xref"], "xref", tol=1e-8)

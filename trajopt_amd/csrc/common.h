@@ -73,7 +73,7 @@ struct RolloutPlanes {
     int first_plane, junk_plane;
     const int32_t* out_bank;   // bank of the multi-buffered gains each problem reads (NULL: plain K / kff)
     // Two-pass line search (driver.hip): pass 1 = cost_only (returns of every alpha, no trajectory written); pass 2 =
-    // sel given: one lane per problem rolls alpha sel[p] (>= 0) out again and writes it to plane first_plane + sel[p]
+    // sel given: one lane per problem rolls alpha sel[p] (>= 0) out again and writes it to plane first_plane
     int cost_only;
     const int32_t* sel;
 };

@@ -149,17 +149,19 @@ __global__ void pending_kernel(DrvArgs a) {
 // ilqr.py:187-231: sequential first-accept over the alphas, evaluated from the precomputed returns.
 // prep_next: another iteration follows in this call - its prep (same thread-per-problem mapping, nothing reads `active`
 // in between) is done here instead of in a launch of its own.
-// staged: pending_kernel has already decided alphas[0] for this problem (sel[p]).
+// ls: line_search_mode() - 1 (staged): pending_kernel has already decided alphas[0] for this problem (sel[p]); 2 (two
+// passes): the accepted trajectory is about to be written to plane 0 of the bank, whatever its alpha.
 // wb: the bank this iteration wrote.
-__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP, int staged, int wb);
-__global__ void select_kernel(DrvArgs a, int prep_next, int staged, int wb) {
+__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP, int ls, int wb);
+__global__ void select_kernel(DrvArgs a, int prep_next, int ls, int wb) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t NP = (size_t)a.ws.nb_problems;
     if (p >= NP) return;
-    select_problem(a, p, NP, staged, wb);
+    select_problem(a, p, NP, ls, wb);
     if (prep_next) prep_problem(a, p, wb ^ 1);
 }
-__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP, int staged, int wb) {
+__device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_t NP, int ls, int wb) {
+    const bool staged = ls == 1;
     const bool first_accepted = staged && a.ws.sel[p] == 0;
     a.ws.sel[p] = -1;
     if (!a.ws.active[p]) return;
@@ -208,7 +210,7 @@ __device__ __forceinline__ void select_problem(const DrvArgs& a, size_t p, size_
         a.ws.sel[p] = sel;
         // ilqr.py:210-217 without a copy: the candidate's plane IS the reference from now on and the bank the backward
         // pass wrote this problem's gains to holds the accepted controller
-        a.ws.ref_plane[p] = wb * a.opt.nb_alphas + sel;
+        a.ws.ref_plane[p] = wb * a.opt.nb_alphas + (ls == 2 ? 0 : sel);
         a.ws.gains_bank[p] = a.ws.out_bank[p];
     } else {
         grow_lambda(lam, dlam, a.opt.sched);
@@ -404,10 +406,11 @@ static int line_search_mode(const trajopt_env_t* env, const trajopt_ilqr_options
     if (opt->staged_line_search == 1) return can_stage ? 1 : 0;
     if (opt->staged_line_search == 2) return can_two ? 2 : 0;
     if (opt->staged_line_search == 0) return 0;
-    if (can_stage && lanes >= 16 * 65536) return 1;
     // (measured, 11 alphas, T = 500: cartpoles win from 16 384 problems on - 3.34 -> 2.76 ms an iteration - and would from
     // ~10 000; double cartpoles, whose second chain is 0.9 ms, lose at 16 384 - 5.90 -> 6.21 - and win 5 % at 32 768)
     if (can_two && lanes >= (env->dm_state + env->dm_act <= 5 ? 5 * 32768 : 6 * 65536)) return 2;
+    // (131 072 cartpoles: staged 21.4 ms an iteration, two passes 16.2)
+    if (can_stage && lanes >= 16 * 65536) return 1;
     return 0;
 }
 
@@ -537,15 +540,16 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
             if (rc != TRAJOPT_OK) return rc;
         }
         if (!two_pass) prof_mark(st, slot, 5);
-        hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a, (it + 1 < nb_iter && !two_pass) ? 1 : 0, staged ? 1 : 0, wb);
+        hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a, (it + 1 < nb_iter && !two_pass) ? 1 : 0, ls, wb);
         if (two_pass) {
             // pass 2: the accepted step size of every problem once more (same arithmetic, same results), this time
-            // written to its plane, which select_kernel has just made the reference; it reads the gains through
+            // written - to plane 0 of the bank, which select_kernel has just made the reference (ONE plane for every
+            // alpha: neighbouring problems stay neighbours in memory); it reads the gains through
             // out_bank, so the next iteration's prep (which moves out_bank on) follows it instead of riding in select.
             // Reported under the "rollout" phase.
             const RolloutPlanes rp2{rp.first_plane, rp.junk_plane, rp.out_bank, 0, ws->sel};
             rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
-                                ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, nullptr, ws->cand_state,
+                                ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                                 ws->cand_action, nullptr, nullptr, nullptr, st, GL, 0, opt->nb_alphas, nullptr, nullptr,
                                 &rp2);
             if (rc != TRAJOPT_OK) return rc;

@@ -36,7 +36,8 @@ struct RolloutArgs {
     // trajopt_backward_io_t::out_bank); NULL: plain arrays
     const int32_t* out_bank;
     // Second pass of the driver's two-pass line search: ONE lane per problem, which rolls out alpha sel[p] again (the
-    // step size select_kernel accepted; < 0: nothing to do) and writes its trajectory; NULL: every (problem, alpha)
+    // step size select_kernel accepted; < 0: nothing to do) and writes its trajectory to plane first_plane; NULL: every
+    // (problem, alpha)
     const int32_t* sel;
 };
 
@@ -116,9 +117,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     int ai;
     bool idle = false;  // no early return before the barrier below
     if (a.sel) {
-        idle = idx >= NP;
-        p = idle ? 0 : idx;
-        const int s = idle ? -1 : a.sel[p];
+        p = idx < NP ? idx : 0;
+        const int s = idx < NP ? a.sel[p] : -1;
         idle = s < 0;
         ai = idle ? a.alpha_begin : s;
     } else if (a.xcd_tiles) {
@@ -198,7 +198,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     const size_t En1 = (size_t)n * (T + 1), En = (size_t)n * T, Em = (size_t)m * T, Enm = (size_t)n * m * T;
     const int kmul = a.out_bank ? TRAJOPT_GAIN_BANKS : 1, bank = gains_bank(a.out_bank, p);
     // candidate planes: alpha slowest (TB: inside this iteration's bank; a lane without a result of its own writes junk_plane)
-    const size_t plane = TB ? (size_t)(live ? a.first_plane + ai : a.junk_plane) : (size_t)ai;
+    // (second pass of the two-pass line search: ONE plane for whatever alpha a problem accepted.  Letting the problems
+    // that accepted none write their own slot of it instead of the junk plane - whole 1 KB runs - changed nothing:
+    // 65 536 cartpoles 7.2 ms an iteration either way.)
+    const size_t plane = TB ? (size_t)(live ? a.first_plane + (a.sel ? 0 : ai) : a.junk_plane) : (size_t)ai;
     double* st = (!TB && a.state) ? a.state + plane * En1 * NP : nullptr;
     double* ac = (!TB && a.action) ? a.action + plane * Em * NP : nullptr;
     double* co = a.cost ? a.cost + (size_t)ai * (size_t)(T + 1) * NP : nullptr;
