@@ -194,7 +194,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     }
     const trajopt_env_t& e = SYS::kStatic ? ev : a.env;
     const int n = SYS::n(e), m = SYS::m(e), T = a.T;
-    const double alpha = a.alphas[ai];
+    // (second pass: a lane without an accepted step size runs along on alpha = 0, i.e. on the reference itself - with a
+    // rejected step size its states may grow until the whole wave takes sincos' big-argument path)
+    const double alpha = (a.sel && idle) ? 0.0 : a.alphas[ai];
     const size_t En1 = (size_t)n * (T + 1), En = (size_t)n * T, Em = (size_t)m * T, Enm = (size_t)n * m * T;
     const int kmul = a.out_bank ? TRAJOPT_GAIN_BANKS : 1, bank = gains_bank(a.out_bank, p);
     // candidate planes: alpha slowest (TB: inside this iteration's bank; a lane without a result of its own writes junk_plane)
