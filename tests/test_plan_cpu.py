@@ -36,9 +36,9 @@ def test_line_search_schedule_by_batch_size():
     # small batches: every (problem, alpha) in one launch, the lone-wave rollout form
     p = _plan("cartpole", 4096)
     assert p["staged_line_search"] == 0 and p["rollout_straight_line"] == 1 and p["fused_quad_bwd"] == 1
-    # from 2.5 waves per SIMD on (dx + du <= 5): returns first, the accepted alpha again
-    assert _plan("cartpole", 14894)["staged_line_search"] == 0
-    assert _plan("cartpole", 14895)["staged_line_search"] == 2
+    # from 1.4 waves per SIMD on (dx + du <= 5): returns first, the accepted alpha again
+    assert _plan("cartpole", 8191)["staged_line_search"] == 0
+    assert _plan("cartpole", 8192)["staged_line_search"] == 2
     p = _plan("cartpole", 65536)
     assert p["staged_line_search"] == 2 and p["rollout_straight_line"] == 0 and p["fused_quad_bwd"] == 2
     assert _plan("pendulum", 65536, T=100)["staged_line_search"] == 2

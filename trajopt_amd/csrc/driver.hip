@@ -398,7 +398,7 @@ int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_optio
 //   2  two passes: the returns of every (problem, alpha) without writing a trajectory, then the accepted step size of
 //      each problem once more, written.  The stores of the nb_alphas - 1 candidates nobody reads are most of what a
 //      large rollout moves (65 536 cartpoles: 14.4 GB of 18.3 per launch); the price is a second latency chain of one
-//      lane per problem, so it is taken from 2.5 waves per SIMD on (small models; 6 for the others).
+//      lane per problem, so it is taken from 1.4 waves per SIMD on (small models; 6 for the others).
 static int line_search_mode(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt, const trajopt_ilqr_workspace_t* ws) {
     const int64_t lanes = ws->nb_problems * (int64_t)opt->nb_alphas;
     const bool can_stage = !opt->argmin_alpha && opt->nb_alphas >= 2 && ws->pending_list && ws->pending_count;
@@ -406,9 +406,10 @@ static int line_search_mode(const trajopt_env_t* env, const trajopt_ilqr_options
     if (opt->staged_line_search == 1) return can_stage ? 1 : 0;
     if (opt->staged_line_search == 2) return can_two ? 2 : 0;
     if (opt->staged_line_search == 0) return 0;
-    // (measured, 11 alphas, T = 500: cartpoles win from 16 384 problems on - 3.34 -> 2.76 ms an iteration - and would from
-    // ~10 000; double cartpoles, whose second chain is 0.9 ms, lose at 16 384 - 5.90 -> 6.21 - and win 5 % at 32 768)
-    if (can_two && lanes >= (env->dm_state + env->dm_act <= 5 ? 5 * 32768 : 6 * 65536)) return 2;
+    // (measured, 11 alphas, T = 500, ms an iteration: cartpoles 8192: 2.21 -> 2.08, 10 240: 2.51 -> 2.18, 16 384: 3.34 ->
+    // 2.76 - while 4096, whose waves have a SIMD each, would pay 0.4 ms for the second chain; double cartpoles, whose
+    // second chain is 0.9 ms, lose at 8192 - 3.52 -> 4.07 - and at 16 384 - 5.90 -> 6.21 - and win 5 % at 32 768)
+    if (can_two && lanes >= (env->dm_state + env->dm_act <= 5 ? 11 * 8192 : 6 * 65536)) return 2;
     // (131 072 cartpoles: staged 21.4 ms an iteration, two passes 16.2)
     if (can_stage && lanes >= 16 * 65536) return 1;
     return 0;
