@@ -454,7 +454,7 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
 typedef struct trajopt_ilqr_plan {
     int32_t structured_cost;   /* 1: closed-form Cxx / Cuu / Cxu formed inside the backward kernel (cost_w)            */
     int32_t fused_quad_bwd;    /* quadratisation and backward pass in one launch: 1 = four problems per wave (fused_qb4.hip,
-                                  small batches), 2 = lane per problem (bwd_tpp.hip, >= 32768 problems); 0 = two launches */
+                                  < 32768 problems), 2 = lane per problem (bwd_tpp.hip, >= 32768 problems); 0 = two launches */
     int32_t staged_line_search;/* 0 one launch; 1: alphas[0] for everybody, the rest for the compacted list of rejecting
                                   problems; 2: returns of every alpha first, then the accepted one again, written     */
     int32_t backward_kernel;   /* TRAJOPT_KERNEL_* family of the backward pass                                         */

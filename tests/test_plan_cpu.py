@@ -39,6 +39,10 @@ def test_line_search_schedule_by_batch_size():
     # from 1.4 waves per SIMD on (dx + du <= 5): returns first, the accepted alpha again
     assert _plan("cartpole", 8191)["staged_line_search"] == 0
     assert _plan("cartpole", 8192)["staged_line_search"] == 2
+    # quadratisation + backward pass in one launch: four problems per wave below 32 768 problems, lane = problem from there
+    assert _plan("cartpole", 16384)["fused_quad_bwd"] == 1 and _plan("cartpole", 32767)["fused_quad_bwd"] == 1
+    assert _plan("cartpole", 32768)["fused_quad_bwd"] == 2
+    assert _plan("double_cartpole", 8192)["fused_quad_bwd"] == 0
     p = _plan("cartpole", 65536)
     assert p["staged_line_search"] == 2 and p["rollout_straight_line"] == 0 and p["fused_quad_bwd"] == 2
     assert _plan("pendulum", 65536, T=100)["staged_line_search"] == 2

@@ -387,12 +387,14 @@ struct FusedLaunch {
     }
 };
 
-// Shapes the fused kernel takes: a built-in model with dx <= 4, du = 1 (pendulum, cartpole), small batches (the
-// four-problems-per-wave recursion saturates the texture addressers beyond ~6k problems, see api.hip), byte offsets
-// inside one array below 2^32.
+// Shapes the fused kernel takes: a built-in model with dx <= 4, du = 1 (pendulum, cartpole), batches below the 32 768
+// problems from which the lane-per-problem fusion (bwd_tpp.hip) takes over, byte offsets inside one array below 2^32.
+// (The four-problems-per-wave recursion ALONE loses to lane = problem beyond ~6k problems - it saturates the texture
+// addressers on its dense inputs, see api.hip - but fused it has no such inputs, and what it replaces is two
+// launches: 8192 cartpoles 0.97 -> 0.45 ms, 16 384 1.21 -> 0.89 ms, 24 576 1.37 ms; 32 768 lane-per-problem 1.70 ms.)
 bool fused_qb4_supported(const trajopt_env_t* env, int T, int64_t NP) {
     if (env->model != TRAJOPT_ENV_PENDULUM && env->model != TRAJOPT_ENV_CARTPOLE) return false;
-    if (env->nb_features != 0 || NP > 6144) return false;
+    if (env->nb_features != 0 || NP >= 32768) return false;
     const int n = env->dm_state;
     return (double)(T + 2) * n * n * (double)NP * 8.0 < 4294967296.0 &&
            (double)TRAJOPT_GAIN_BANKS * (T + 1) * n * (double)NP * 8.0 < 4294967296.0;
