@@ -10,28 +10,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from trajopt_amd import backward  # noqa: E402
-from trajopt_amd.layout import device_shape  # noqa: E402
+from trajopt_amd.synthetic import device_backward_inputs  # noqa: E402
 
 
 def make(n, m, T, N, layout, affine, dev="cuda"):
-    g = torch.Generator(device=dev)
-    g.manual_seed(1337)
-
-    def rn(scale, *logical):
-        x = torch.randn(device_shape(logical, layout), generator=g, dtype=torch.float64, device=dev)
-        return x.mul_(scale)
-
-    def add_eye(x, k, scale):
-        I = scale * torch.eye(k, dtype=torch.float64, device=dev)
-        x += I.reshape(1, 1, k, k) if layout == 0 else I.reshape(1, k, k, 1)
-        return x
-
-    d = dict(A=add_eye(rn(0.01 / n ** 0.5, N, n, n, T), n, 1.0), B=rn(0.01, N, n, m, T),
-             Cxx=add_eye(rn(0.0, N, n, n, T + 1), n, 1.0), Cuu=add_eye(rn(0.0, N, m, m, T + 1), m, 1e-2),
-             Cxu=rn(0.01, N, n, m, T + 1), cx=rn(1.0, N, n, T + 1), cu=rn(1.0, N, m, T + 1))
-    if affine:
-        d["c"] = rn(0.01, N, n, T)
-    return d
+    return device_backward_inputs(n, m, T, N, layout, affine=affine, dev=dev)
 
 
 def main():

@@ -33,8 +33,9 @@ def main():
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and l.rstrip().split(":")[0].endswith(key) or
                  (l.startswith("_Z") and key in l.split(":")[0]))
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
-    body = lines[start:end + 1]
+    # the function's end, not its first s_endpgm: a kernel with an early exit has one in the middle of its body
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    body = lines[start:end]
     labels = {}
     insts = []
     for l in body:
@@ -54,11 +55,13 @@ def main():
         if m:
             tgt = m.group(1) or m.group(2)
             if tgt in labels and labels[tgt] <= i:
-                loops.append((labels[tgt], i))
+                loops.append((labels[tgt], i, bool(m.group(1))))
     out = {"kernel": key, "total_instructions": len(insts), "loops": []}
-    for a, b in loops:
+    for a, b, cond in loops:
         c = collections.Counter(classify(s.split()[0]) for s in insts[a:b + 1])
-        d = {"first": a, "last": b, "instructions": b - a + 1, "by_category": dict(sorted(c.items(), key=lambda kv: -kv[1]))}
+        # conditional: closed by an s_cbranch (a loop); an unconditional backward s_branch is an out-of-line block
+        # (a slow path placed behind the loop) jumping back into it
+        d = {"first": a, "last": b, "conditional": cond, "instructions": b - a + 1, "by_category": dict(sorted(c.items(), key=lambda kv: -kv[1]))}
         d["valu"] = sum(v for k, v in c.items() if k.startswith(("fp64", "valu")))
         d["fp64_flops_per_lane"] = 2 * c.get("fp64_fma", 0) + c.get("fp64_mul", 0) + c.get("fp64_add", 0)
         out["loops"].append(d)

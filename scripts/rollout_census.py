@@ -2,9 +2,10 @@
 
   python scripts/rollout_census.py [out.json]
 
-Compiles csrc/rollout.hip to assembly, takes the driver's cartpole kernel (FAST, time-blocked, straight-line blocks:
-the variant bench.py's workload launches), finds its block loop (8 steps per trip) and counts the instructions by
-category.  bench.py uses `fp64_flops_per_lane_step` for the rollout's compute roofline; the stamp ties the file to the
+Compiles csrc/rollout.hip to assembly, takes each model's driver kernel in its straight-line form (FAST, time-blocked,
+8 steps per trip of the block loop: the variant bench.py's C2 workload launches; the rolled and returns-only forms of
+larger batches run the same arithmetic per step around different loop / addressing code) and counts the instructions
+of that loop by category.  bench.py uses `fp64_flops_per_lane_step` for the rollout's compute roofline; the stamp ties the file to the
 sources it was made from."""
 import json
 import os
@@ -16,13 +17,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from trajopt_amd import _lib  # noqa: E402
 
+# <SYS, MINOR, KMINOR (the gains' layout in the driver: PROBLEM_MINOR for dx <= 6), FAST, TB, UNR>
 KERNELS = {"cartpole": "rollout_kernelINS_7SysPhysILi2EEELb1ELb1ELb1ELb1ELb1ELb0EEEvNS_11RolloutArgsE",
-           "pendulum": "rollout_kernelINS_7SysPhysILi1EEELb1ELb1ELb1ELb1ELb1ELb0EEEvNS_11RolloutArgsE"}
+           "pendulum": "rollout_kernelINS_7SysPhysILi1EEELb1ELb1ELb1ELb1ELb1ELb0EEEvNS_11RolloutArgsE",
+           "double_cartpole": "rollout_kernelINS_7SysPhysILi3EEELb1ELb1ELb1ELb1ELb1ELb0EEEvNS_11RolloutArgsE",
+           "quadrotor": "rollout_kernelINS_7SysPhysILi5EEELb1ELb0ELb1ELb1ELb1ELb0EEEvNS_11RolloutArgsE"}
+
+
+ROLLOUT_SOURCES = _lib.ROLLOUT_SOURCES
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_rollout_isa_census.json")
-    res = {"stamp": _lib.source_stamp(), "steps_per_trip": 8, "kernels": {},
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_rollout_isa_census.json")
+    res = {"stamp": _lib.source_stamp(), "rollout_stamp": _lib.source_stamp(ROLLOUT_SOURCES), "steps_per_trip": 8, "kernels": {},
            "note": "block loop of the driver's rollout kernel (8 steps per trip, straight-line); counts are "
                    "instructions per wave; fp64 flops per lane: 2 per fma, 1 per mul / add"}
     with tempfile.TemporaryDirectory() as d:
@@ -33,7 +40,8 @@ def main():
             js = os.path.join(d, env + ".json")
             subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "isa_census.py"), asm, key, js])
             loops = json.load(open(js))["loops"]
-            big = max(loops, key=lambda l: l["instructions"])          # the outermost loop = the block loop
+            # the largest loop closed by a conditional branch = the block loop (8 straight-line steps)
+            big = max((l for l in loops if l["conditional"]), key=lambda l: l["instructions"])
             per_step = {k: v / 8.0 for k, v in big["by_category"].items()}
             res["kernels"][env] = {"mangled": key, "trip_instructions": big["instructions"],
                                    "instructions_per_step": big["instructions"] / 8.0,

@@ -115,9 +115,14 @@ EXPORTS = (
     "trajopt_profile_begin", "trajopt_profile_end", "trajopt_profile_select",
 )
 
-def source_stamp():
+# what the rollout kernel's arithmetic depends on (the stamp of profiles/*_rollout_isa_census.json)
+ROLLOUT_SOURCES = ("rollout.hip", "sys.h", "env_models.h", "common.h", "trajopt_env.h")
+
+
+def source_stamp(only=None):
     """Hash of the kernel sources (csrc/*.hip, *.h, include/*.h): measurements kept under profiles/ carry the stamp
-    of the sources they were taken on, and bench.py only quotes one whose stamp is the current one."""
+    of the sources they were taken on, and bench.py only quotes one whose stamp is the current one.
+    only: restrict to these file names (the ISA census of one kernel depends on its own sources only)."""
     import glob
     import hashlib
     h = hashlib.sha1()
@@ -125,6 +130,8 @@ def source_stamp():
     files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
                    glob.glob(os.path.join(root, "include", "*.h")))
     for f in files:
+        if only is not None and os.path.basename(f) not in only:
+            continue
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:12]

@@ -72,3 +72,32 @@ def bsp_inputs(b, m, T, N, seed=SEED, coupling=1e-2):
     for k, cols in (("T", b), ("U", bb), ("V", m), ("X", b), ("Y", bb), ("Z", m)):
         out[k] = np.ascontiguousarray(coupling * rng.standard_normal((N, T, cols, bb))).transpose(0, 3, 2, 1)
     return out
+
+
+def device_backward_inputs(n, m, T, N, layout, affine=False, dev="cuda", seed=SEED):
+    """Dense backward-pass inputs generated ON THE DEVICE in `layout` (benchmarks at sizes the host generator above
+    would take minutes for): A = I + 0.01 G / sqrt(n), B = 0.01 N(0,1), Cxx = I, Cuu = 1e-2 I, Cxu = 0.01 N(0,1),
+    cx, cu ~ N(0,1), c = 0.01 N(0,1) (Riccati form) - SPD Cxx / Cuu by construction.  -> dict of torch tensors."""
+    import torch
+    from .layout import device_shape
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+
+    def rn(scale, *logical):
+        shp = device_shape(logical, layout)
+        if scale == 0.0:
+            return torch.zeros(shp, dtype=torch.float64, device=dev)
+        x = torch.randn(shp, generator=g, dtype=torch.float64, device=dev)
+        return x.mul_(scale)
+
+    def add_eye(x, k, scale):
+        I = scale * torch.eye(k, dtype=torch.float64, device=dev)
+        x += I.reshape(1, 1, k, k) if layout == 0 else I.reshape(1, k, k, 1)
+        return x
+
+    d = dict(A=add_eye(rn(0.01 / n ** 0.5, N, n, n, T), n, 1.0), B=rn(0.01, N, n, m, T),
+             Cxx=add_eye(rn(0.0, N, n, n, T + 1), n, 1.0), Cuu=add_eye(rn(0.0, N, m, m, T + 1), m, 1e-2),
+             Cxu=rn(0.01, N, n, m, T + 1), cx=rn(1.0, N, n, T + 1), cu=rn(1.0, N, m, T + 1))
+    if affine:
+        d["c"] = rn(0.01, N, n, T)
+    return d
