@@ -85,8 +85,8 @@ int trajopt_ilqr_backward_pass_host(const double* Cxx_host, const double* cx_hos
                                     int* failed);
 
 /* Allocation-free variant of trajopt_ilqr_backward_pass_host.  It has NO counterpart in the reference: it is for
- * callers that cannot allocate device memory - code under HIP graph capture, tight serving / MPC loops, harnesses
- * that forbid hipMalloc.  Same arguments, results and kernels as trajopt_ilqr_backward_pass_host, plus the stream
+ * callers that cannot allocate device memory - tight serving / MPC loops, harnesses that forbid hipMalloc (NOT stream
+ * capture: the call copies from / to pageable host memory and synchronises the stream, both illegal while capturing).  Same arguments, results and kernels as trajopt_ilqr_backward_pass_host, plus the stream
  * the copies and kernels run on (NULL = the default stream; the call synchronises that stream before returning).
  * The device staging (inputs | outputs | lmbda, diverge) lives in a static device array of the library of
  * TRAJOPT_NOALLOC_MAX_DOUBLES doubles (4 MiB, held per GPU until the process ends) instead of hipMalloc/hipFree:
@@ -174,6 +174,10 @@ int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg,
  * matrix product (the reference's elementwise `*` at :123 coincides with it only for dm_act == 1).
  * Outputs: K(m,n,T) kff(m,T) V(n,n,T+1) v(n,T+1).  status[p] (may be NULL): 0 ok, t+1 if Quu was
  * singular at step t (np.linalg.inv would raise).
+ * Concurrency of the batched entry: with status non-NULL a call touches only memory its caller passed in (the
+ * matrix-core sweep hands the problems it cannot take - asymmetric Cxx slice, non-positive pivot - to the generic
+ * kernel through status[p] itself), so calls on different streams or threads of one GPU may overlap freely.  With
+ * status == NULL that hand-over uses one static flag array per GPU: at most one such call per GPU at a time.
  * ---------------------------------------------------------------------------------------------- */
 int trajopt_riccati_backward_pass_host(const double* Cxx_host, const double* cx_host, const double* Cuu_host,
                                        const double* cu_host, const double* Cxu_host, const double* A_host,

@@ -378,3 +378,47 @@ def test_riccati_sweep_does_not_depend_on_the_kernel_for_asymmetric_or_indefinit
         assert_close(L.from_device(o["K"], 0)[p], K, "K of problem %d" % p)
         assert_close(L.from_device(o["V"], 0)[p], V, "V of problem %d" % p)
         assert_close(L.from_device(o["v"], 0)[p], v, "v of problem %d" % p)
+
+
+def test_riccati_sweeps_overlapping_on_two_streams_keep_their_own_fallback_flags(oracle):
+    """the matrix-core sweep hands a problem it cannot take (here: an indefinite Quu) to the generic kernel
+    through a per-problem flag.  That flag lives in the caller's status array, so two calls that overlap on one GPU -
+    one batch with such a problem, one without, each on its own stream, several rounds - cannot clear or steal each
+    other's flags; a call WITHOUT a status array (the per-device static flags) gives the same results on its own."""
+    import torch
+    from trajopt_amd import backward, layout as L, synthetic as S
+    n, m, T, N = 33, 7, 40, 24
+    stacks = [S.backward_inputs(n, m, T, N, seed=41, affine=True), S.backward_inputs(n, m, T, N, seed=42, affine=True)]
+    for p in (3, 17):
+        stacks[0]["Cuu"][p][...] = -stacks[0]["Cuu"][p] - 5.0 * np.eye(m)[:, :, None]   # indefinite but invertible
+    dev = [{k: L.to_device(v, 0) for k, v in st.items()} for st in stacks]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for rnd in range(6):
+        for i in (rnd % 2, 1 - rnd % 2):   # alternate who goes first
+            with torch.cuda.stream(streams[i]):
+                d = dev[i]
+                outs[i].append(backward.riccati_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"],
+                                                              d["c"], n, m, T, N, 0))
+    torch.cuda.synchronize()
+    refs = []
+    for i in range(2):
+        refs.append({})
+        for p in (0, 3, 17, N - 1):
+            q = S.problem(stacks[i], p)
+            refs[i][p] = oracle.riccati_backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], q["c"], n, m, T)
+    for i in range(2):
+        for o in outs[i]:
+            assert not o["status"].cpu().numpy().any()
+            assert torch.equal(o["K"], outs[i][0]["K"]) and torch.equal(o["V"], outs[i][0]["V"])   # every round the same bits
+        for p, (K, kff, V, v) in refs[i].items():
+            assert_close(L.from_device(outs[i][0]["K"], 0)[p], K, "K of batch %d problem %d" % (i, p))
+            assert_close(L.from_device(outs[i][0]["V"], 0)[p], V, "V of batch %d problem %d" % (i, p))
+            assert_close(L.from_device(outs[i][0]["kff"], 0)[p], kff, "kff of batch %d problem %d" % (i, p))
+    d = dev[0]
+    o = backward.riccati_backward_pass(d["Cxx"], d["cx"], d["Cuu"], d["cu"], d["Cxu"], d["A"], d["B"], d["c"], n, m, T, N, 0,
+                                       with_status=False)
+    torch.cuda.synchronize()
+    assert o["status"] is None
+    assert torch.equal(o["K"], outs[0][0]["K"]) and torch.equal(o["V"], outs[0][0]["V"]) and torch.equal(o["v"], outs[0][0]["v"])

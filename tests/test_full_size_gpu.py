@@ -345,3 +345,75 @@ def test_two_pass_line_search_falls_back_where_there_is_no_returns_only_rollout(
         assert s.plan()["staged_line_search"] == 0
         s.run(nb_iter=2)
         assert np.all(np.isfinite(s.host("last_return")))
+
+
+_NCCL_RANK = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from trajopt_amd import envs
+from trajopt_amd.ilqr import BatchedILQR
+from trajopt_amd.sharding import ShardedILQR
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+N, T, iters = 96, 60, 4
+rng = np.random.Generator(np.random.PCG64(5))
+x0 = np.array([0., np.pi, 0., 0.])[None] + 1e-2 * rng.standard_normal((N, 4))
+kff0 = 1e-4 * rng.standard_normal((N, 1, T))
+sh = ShardedILQR(envs.make("cartpole", dt=0.02), T, x0, kff_init=kff0, action_penalty=1e-5)
+out = sh.run(nb_iter=iters)
+assert out["last_return"].is_cuda and out["status"].is_cuda, "RCCL gathers device tensors in place"
+b = BatchedILQR(envs.make("cartpole", dt=0.02), T, x0, kff_init=kff0, action_penalty=1e-5)
+b.run(nb_iter=iters)
+ok = (np.array_equal(out["last_return"].cpu().numpy(), b.host("last_return")) and
+      np.array_equal(out["status"].cpu().numpy(), b.host("status")) and np.array_equal(out["iters"].cpu().numpy(), b.host("iters")))
+tt = torch.tensor([1.25], dtype=torch.float64, device="cuda")
+dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+dist.barrier()
+print(json.dumps({"ok": bool(ok), "backend": dist.get_backend(), "max": float(tt.item()),
+                  "total": out["progress"]["total_cost"], "want_total": float(b.host("last_return").sum())}))
+dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def test_rccl_process_group_of_one_rank_on_the_device():
+    """the `nccl` (= RCCL) branch of the sharded solver on the real device - a one-rank process
+    group, device tensors through all_gather / all_reduce / barrier (mistakes a gloo rehearsal cannot see) - in a child
+    process so that this one keeps no process group."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _NCCL_RANK, root, str(_free_port())], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["ok"] and d["backend"] == "nccl" and d["max"] == 1.25
+    assert d["total"] == pytest.approx(d["want_total"], rel=1e-12)
+
+
+def test_bench_collective_path_with_rccl_at_world_size_one():
+    """bench.py's multi-rank path (RCCL barrier, max over ranks on a device tensor, one device per rank checked) with
+    ONE rank on the device: what the driver's N > 1 runs execute, minus the other ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRAJOPT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--instances", "512",
+                        "--horizon", "48", "--no-configs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and len(d["rank_devices"]) == 1 and d["value"] > 0

@@ -513,3 +513,35 @@ def test_riccati_forward_pass_and_rollout_equal_the_stepwise_loop():
     assert_close(data["x"], xs, "x"); assert_close(data["u"], us, "u"); assert_close(data["xn"], xns, "xn")
     assert_close(data["c"][-1], cs[-1], "final cost")
     assert_close(data["c"][:-1], np.repeat(cs[:-1, -1:], E, axis=1), "step costs (riccati.py:71: the last episode's row)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,T", [("double_cartpole", dict(dt=0.01, uw=[1e-5]), 21), ("quadrotor", dict(dt=0.02, uw=[1e-3]), 21),
+                                       ("cartpole", dict(dt=0.02, uw=[1e-5]), 19), ("pendulum", dict(dt=0.05, uw=[1e-5]), 13)])
+def test_two_pass_line_search_is_bitwise_the_one_launch_line_search_on_every_model(oracle, name, kw, T):
+    """the two-pass line search takes the returns from the returns-only rollout and the accepted trajectory
+    from ANOTHER instantiation (time-blocked, straight-line or rolled; for the quadrotor the direct-store form with
+    PROBLEM_MAJOR gains).  Forced (mode 2) on every model, with a horizon that is not a multiple of the 8-step block
+    (the flush of the partial last block in pass 2), every output must equal the one-launch line search bit for bit."""
+    from trajopt_amd.ilqr import BatchedILQR
+    pe, oe = _pair(name, **kw)
+    N = 300
+    rng = np.random.Generator(np.random.PCG64(77))
+    x0 = np.asarray(pe.x0)[None] + 0.2 * _rand_state(name, rng, N)
+    kff0 = 1e-2 * rng.standard_normal((N, pe.dm_act, T))
+    keys = ("xref", "uref", "K", "kff", "lmbda", "dlmbda", "status", "iters", "last_return", "alpha")
+    runs = {}
+    for mode in (2, 0):
+        s = BatchedILQR(pe, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False, staged_line_search=mode)
+        assert s.plan()["staged_line_search"] == mode
+        s.run(nb_iter=3)
+        traces = s.run(nb_iter=2)
+        runs[mode] = dict(traces=traces, **{k: s.host(k) for k in keys})
+    a, b = runs[2], runs[0]
+    assert a["traces"] == b["traces"]
+    for k in keys:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert max(len(t) for t in a["traces"]) > 1, "some problem must accept a step"
+    p = int(np.argmax([len(t) for t in a["traces"]]))
+    r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=5)
+    assert abs(a["last_return"][p] - r["last_return"]) <= 1e-9 * abs(r["last_return"])

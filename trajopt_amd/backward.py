@@ -78,8 +78,10 @@ def ilqr_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, dm_state, dm_act
     return o
 
 
-def riccati_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, c, dm_state, dm_act, nb_steps, nb_problems, layout):
-    """TV-LQR sweep of /root/reference/trajopt/riccati/riccati.py:100-126 for a batch -> K, kff, V, v, status."""
+def riccati_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, c, dm_state, dm_act, nb_steps, nb_problems, layout,
+                          with_status=True):
+    """TV-LQR sweep of /root/reference/trajopt/riccati/riccati.py:100-126 for a batch -> K, kff, V, v, status.
+    with_status=False passes status = NULL (then at most one such call per GPU at a time: include/trajopt_amd.h)."""
     import torch
     _lib.require_gpu()
     n, m, T, N = dm_state, dm_act, nb_steps, nb_problems
@@ -90,7 +92,7 @@ def riccati_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, c, dm_state, dm_act, nb_s
     dev = Cxx.device
     o = dict(K=empty((N, m, n, T), layout, dev, zero=True), kff=empty((N, m, T), layout, dev, zero=True),
              V=empty((N, n, n, T + 1), layout, dev, zero=True), v=empty((N, n, T + 1), layout, dev, zero=True),
-             status=torch.zeros(N, dtype=torch.int32, device=dev))
+             status=torch.zeros(N, dtype=torch.int32, device=dev) if with_status else None)
     check(lib().trajopt_riccati_backward_pass_batched(
         dptr(Cxx), dptr(cx), dptr(Cuu), dptr(cu), dptr(Cxu), dptr(A), dptr(B), dptr(c), n, m, T, C.c_int64(N),
         int(layout), dptr(o["V"]), dptr(o["v"]), dptr(o["K"]), dptr(o["kff"]), dptr(o["status"]), stream_ptr()))

@@ -481,6 +481,16 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
     // candidates into bank it % 2 and its gains into bank out_bank[p] (it % 2 for all but the rejecting problems).
     const RefView rv{ws->ref_plane, ws->cand_state, ws->cand_action, ws->xref, ws->uref};
     io.out_bank = ws->out_bank;
+    // xref / uref / K / kff of the accepted iterate (and both maps back to -1, the state of a fresh workspace)
+    auto publish = [&]() {
+        if (gminor) hipLaunchKernelGGL(publish_kernel<true>, g2, dim3(256), 0, st, a, 1);
+        else hipLaunchKernelGGL(publish_kernel<false>, g2, dim3(256), 0, st, a, 1);
+        hipLaunchKernelGGL(published_kernel, dim3(g1), dim3(256), 0, st, a);
+    };
+    // An error inside the loop still publishes what has been accepted so far: the maps then point at nothing
+    // a later call could overwrite, and xref / uref / K / kff are those of the last accepted iterate.  The caller
+    // should nevertheless treat the workspace as needing a reset (BatchedILQR marks itself uninitialised).
+    auto fail = [&](int code) { publish(); (void)hipGetLastError(); return code; };
     for (int it = 0; it < nb_iter; ++it) {
         const int slot = (g_prof.on && g_prof.used < g_prof.cap) ? g_prof.used++ : -1;
         const int wb = it & 1;
@@ -493,20 +503,20 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
             // handed over through LDS (fused_qb4.hip); reported under the "backward" phase
             prof_mark(st, slot, 2);
             rc = launch_fused_qb4(env, io, opt->reg, T, NP, 1, opt->sched, ws->xref, ws->uref, &rv, st);
-            if (rc != TRAJOPT_OK) return rc;
+            if (rc != TRAJOPT_OK) return fail(rc);
         } else if (fused_lane) {
             // large batches of the same models: lane = problem, the expansion in registers (bwd_tpp.hip)
             prof_mark(st, slot, 2);
             rc = launch_fused_tpp(env, io, opt->reg, T, NP, 1, opt->sched, ws->xref, ws->uref, &rv, st);
-            if (rc != TRAJOPT_OK) return rc;
+            if (rc != TRAJOPT_OK) return fail(rc);
         } else {
             rc = launch_quadratize(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, 0, ws->xref, ws->uref, ws->weighting,
                                    ws->active, ws->A, ws->B, nullptr, structured ? nullptr : ws->Cxx, ws->cx,
                                    structured ? nullptr : ws->Cuu, ws->cu, structured ? nullptr : ws->Cxu, st, &rv, GL);
-            if (rc != TRAJOPT_OK) return rc;
+            if (rc != TRAJOPT_OK) return fail(rc);
             prof_mark(st, slot, 2);
             rc = trajopt_ilqr_backward_pass_batched(&io, opt->reg, n, m, T, NP, GL, 1, &opt->sched, st);
-            if (rc != TRAJOPT_OK) return rc;
+            if (rc != TRAJOPT_OK) return fail(rc);
         }
         if (!gminor) hipLaunchKernelGGL(gnorm_major_kernel, dim3((unsigned)NP), dim3(64), 0, st, a);
         prof_mark(st, slot, 3);
@@ -519,26 +529,29 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
                                 ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                                 ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 0, opt->nb_alphas,
                                 nullptr, nullptr, &rp1);
-            if (rc != TRAJOPT_OK) return rc;
+            if (rc != TRAJOPT_OK) return fail(rc);
         } else if (!staged) {
             rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
                                 ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                                 ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 0, opt->nb_alphas,
                                 nullptr, nullptr, &rp);
-            if (rc != TRAJOPT_OK) return rc;
+            if (rc != TRAJOPT_OK) return fail(rc);
         } else {
             rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
                                 ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                                 ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 0, 1, nullptr, nullptr,
                                 &rp);
-            if (rc != TRAJOPT_OK) return rc;
-            TRAJOPT_HIP_CHECK(hipMemsetAsync(ws->pending_count, 0, sizeof(int32_t), st));
+            if (rc != TRAJOPT_OK) return fail(rc);
+            if (const hipError_t e = hipMemsetAsync(ws->pending_count, 0, sizeof(int32_t), st); e != hipSuccess) {
+                set_hip_error(e, "hipMemsetAsync(pending_count)");
+                return fail(TRAJOPT_ERR_HIP);
+            }
             hipLaunchKernelGGL(pending_kernel, dim3(g1), dim3(256), 0, st, a);
             rc = launch_rollout(env, T, NP, TRAJOPT_LAYOUT_PROBLEM_MINOR, ws->x0, ws->cand_K, ws->cand_kff, ws->xref,
                                 ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                                 ws->cand_action, nullptr, ws->cand_ret, ws->cand_finite, st, GL, 1, opt->nb_alphas,
                                 ws->pending_list, ws->pending_count, &rp);
-            if (rc != TRAJOPT_OK) return rc;
+            if (rc != TRAJOPT_OK) return fail(rc);
         }
         if (!two_pass) prof_mark(st, slot, 5);
         hipLaunchKernelGGL(select_kernel, dim3(g1), dim3(256), 0, st, a, (it + 1 < nb_iter && !two_pass) ? 1 : 0, ls, wb);
@@ -553,7 +566,7 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
                                 ws->uref, ws->weighting, opt->alphas, opt->nb_alphas, ws->active, ws->cand_state,
                                 ws->cand_action, nullptr, nullptr, nullptr, st, GL, 0, opt->nb_alphas, nullptr, nullptr,
                                 &rp2);
-            if (rc != TRAJOPT_OK) return rc;
+            if (rc != TRAJOPT_OK) return fail(rc);
             prof_mark(st, slot, 5);
             if (it + 1 < nb_iter) hipLaunchKernelGGL(prep_kernel, dim3(g1), dim3(256), 0, st, a, wb ^ 1);
         }
@@ -561,14 +574,13 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
             if (gminor) hipLaunchKernelGGL(promote_value_kernel<true>, g2, dim3(256), 0, st, a);
             else hipLaunchKernelGGL(promote_value_kernel<false>, g2, dim3(256), 0, st, a);
         }
-        if (it == nb_iter - 1) {   // xref / uref / K / kff of the accepted iterate, once per call
-            if (gminor) hipLaunchKernelGGL(publish_kernel<true>, g2, dim3(256), 0, st, a, 1);
-            else hipLaunchKernelGGL(publish_kernel<false>, g2, dim3(256), 0, st, a, 1);
-            hipLaunchKernelGGL(published_kernel, dim3(g1), dim3(256), 0, st, a);
-        }
+        if (it == nb_iter - 1) publish();   // once per call
         prof_mark(st, slot, 6);
         // a failed launch is reported in the iteration it happens in, not after the remaining ones ran on its garbage
-        TRAJOPT_HIP_CHECK(hipGetLastError());
+        if (const hipError_t e = hipGetLastError(); e != hipSuccess) {
+            set_hip_error(e, "launch inside trajopt_ilqr_iterate");
+            return fail(TRAJOPT_ERR_HIP);
+        }
     }
     return TRAJOPT_OK;
 }

@@ -32,12 +32,19 @@ struct Ric64Args {
     const double *Cxx, *cx, *Cuu, *cu, *Cxu, *A, *B, *c;
     double *V, *v, *K, *kff;
     int32_t* status;
-    int32_t* redo;   // [nb_problems]: non-zero = this problem belongs to the generic kernel (set by the sweep: asymmetric Cxx slice or non-positive pivot)
+    // [nb_problems], only when status is NULL: non-zero = this problem belongs to the generic kernel (set by the sweep:
+    // asymmetric Cxx slice or non-positive pivot).  With a status array the flag travels in status[p] (kRicRedo), memory
+    // the CALLER owns: calls that overlap on one GPU then share nothing.
+    int32_t* redo;
     int n, m, T;
 };
 
-// Per-device flags of the problems handed to the generic kernel, in a static array of the code object (the batched
-// entry points never allocate): resolved once per device like the staging of the allocation-free entry point.
+// status[p] of a problem the sweep hands to the generic kernel; that kernel (bwd_wg.hip, `only`) runs the problems whose
+// entry is non-zero and overwrites it with the final status.
+constexpr int32_t kRicRedo = INT32_MIN;
+// Callers that pass status = NULL have no memory of their own for that flag: for them it lives in a per-device static
+// array of the code object (the batched entry points never allocate), resolved once per device like the staging of the
+// allocation-free entry point - and calls WITHOUT a status array that overlap on one GPU race on it (trajopt_amd.h).
 constexpr int kRicMaxProblems = 1 << 18;
 static __device__ int32_t ric_redo_flags[kRicMaxProblems];
 static std::mutex g_ric_mutex;
@@ -274,8 +281,8 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
     __syncthreads();
     if (S.asym != 0) {   // block-uniform: the generic kernel takes this problem
         if (tid == 0) {
-            a.redo[p] = 1;
-            if (a.status) a.status[p] = 0;
+            if (a.status) a.status[p] = kRicRedo;
+            else a.redo[p] = 1;
         }
         return;
     }
@@ -542,8 +549,8 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 #endif
     // a non-positive pivot: Quu is singular or indefinite - the generic kernel's pivoted LU tells which (riccati.py:118)
     if (tid == 0) {
-        if (bad >= 0) a.redo[p] = 1;
-        if (a.status) a.status[p] = 0;
+        if (a.status) a.status[p] = bad >= 0 ? kRicRedo : 0;
+        else if (bad >= 0) a.redo[p] = 1;
     }
 }
 
@@ -559,10 +566,12 @@ int launch_riccati_mfma64(const double* Cxx, const double* cx, const double* Cuu
     if ((double)n * n * (double)(T + 1) * 8.0 >= 4294967296.0 - 1024.0) return TRAJOPT_OK;   // 32-bit offsets inside a problem's slices
     if (NP > kRicMaxProblems) return TRAJOPT_OK;   // (more problems than flags: the generic kernel takes them all)
     int32_t* redo = nullptr;
-    const int rc = ric_flags(&redo);
-    if (rc != TRAJOPT_OK) return rc;
+    if (!status) {   // no caller-owned flag memory: the per-device static array (one such call per GPU at a time)
+        const int rc = ric_flags(&redo);
+        if (rc != TRAJOPT_OK) return rc;
+        TRAJOPT_HIP_CHECK(hipMemsetAsync(redo, 0, (size_t)NP * sizeof(int32_t), st));
+    }
     *handled = true;
-    TRAJOPT_HIP_CHECK(hipMemsetAsync(redo, 0, (size_t)NP * sizeof(int32_t), st));
     Ric64Args a{Cxx, cx, Cuu, cu, Cxu, A, B, c, V, v, K, kff, status, redo, n, m, T};
     const size_t lds = sizeof(Ric64Lds);
     TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)ric_mfma64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -570,7 +579,7 @@ int launch_riccati_mfma64(const double* Cxx, const double* cx, const double* Cuu
     hipLaunchKernelGGL(ric_mfma64_kernel, dim3((unsigned)NP), dim3(256), lds, st, a);
     TRAJOPT_HIP_CHECK(hipGetLastError());
     // the flagged problems, by the kernel without those assumptions (a workgroup of an unflagged problem leaves at once)
-    return launch_riccati_wg(Cxx, cx, Cuu, cu, Cxu, A, B, c, n, m, T, NP, TRAJOPT_LAYOUT_PROBLEM_MAJOR, V, v, K, kff, status, st, redo);
+    return launch_riccati_wg(Cxx, cx, Cuu, cu, Cxu, A, B, c, n, m, T, NP, TRAJOPT_LAYOUT_PROBLEM_MAJOR, V, v, K, kff, status, st, status ? status : redo);
 }
 
 }  // namespace trajopt

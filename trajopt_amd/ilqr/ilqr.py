@@ -241,8 +241,12 @@ class BatchedILQR:
     def iterate(self, nb_iter=1):
         """`nb_iter` iterations of ilqr.py:151-231 for every problem still running; asynchronous."""
         self._reserve_trace(nb_iter)
-        check(lib().trajopt_ilqr_iterate(C.byref(self._struct), C.byref(self._opt), C.byref(self._ws), int(nb_iter),
-                                         stream_ptr()))
+        try:
+            check(lib().trajopt_ilqr_iterate(C.byref(self._struct), C.byref(self._opt), C.byref(self._ws), int(nb_iter),
+                                             stream_ptr()))
+        except _lib.TrajoptError:
+            self._initialised = False   # a launch failed part-way: the workspace needs reset() before it is used again
+            raise
 
     def run(self, nb_iter=25, verbose=False):
         """iLQR.run for the whole batch.  Returns the list of per-problem cost traces (ilqr.py:137,237)."""

@@ -73,10 +73,16 @@ class Riccati:
         (trajopt_riccati_forward_pass_batched): the initial states and the per-step noise are drawn here, with the
         env's own generator in the order the reference's loops consume it (reset, then one draw per step, episode after
         episode: riccati.py:66-72,91-95), uploaded once and added on the device.
+        The noise of an episode is drawn in one call with u.noise() taken once: that equals the reference's per-step
+        draws while noise(x, u) is constant, which holds for every env of the reference (e.g. lqr_v0.py:68-69).
         -> state (n, T + 1, N), action (m, T, N), xnext (n, T, N), cost (T + 1, N)"""
         import torch
         _lib.require_gpu()
-        u = env.unwrapped
+        u = env.unwrapped if hasattr(env, "unwrapped") else env
+        if not hasattr(u, "struct"):
+            raise _lib.TrajoptError(
+                "Riccati.rollout / forward_pass integrate the episodes on the device and need an env with a device model "
+                "(trajopt_amd.envs); %s has no struct()" % type(u).__name__)
         N, n, m, T = int(nb_episodes), self.dm_state, self.dm_act, self.nb_steps
         x0, noise = np.zeros((N, n)), np.zeros((N, T, n))
         for ep in range(N):
