@@ -328,16 +328,59 @@ def test_structured_cost_is_refused_where_no_kernel_takes_it():
     import torch
     from trajopt_amd import backward, layout as L, synthetic as S
     from trajopt_amd._lib import TrajoptError, lib
-    n, m, T, N = 12, 4, 8, 3
+    n, m, T, N = 20, 5, 8, 3        # workgroup-per-problem kernel: dense cost arrays only
     assert lib().trajopt_backward_supports_structured_cost(n, m, T, C.c_int64(N), 1) == 0
     assert lib().trajopt_backward_supports_structured_cost(4, 1, 500, C.c_int64(4096), 1) == 1
-    assert lib().trajopt_backward_supports_structured_cost(4, 1, 500, C.c_int64(4096), 0) == 0
+    assert lib().trajopt_backward_supports_structured_cost(4, 1, 500, C.c_int64(4096), 0) == 1    # matrix-core kernel
+    assert lib().trajopt_backward_supports_structured_cost(12, 4, 500, C.c_int64(4096), 0) == 1
     stack = S.backward_inputs(n, m, T, N, seed=1)
     d = {k: L.to_device(stack[k], 1) for k in ("cx", "cu", "A", "B")}
     lam = torch.ones(N, dtype=torch.float64, device="cuda")
     with pytest.raises(TrajoptError):
         backward.ilqr_backward_pass(None, d["cx"], None, d["cu"], None, d["A"], d["B"], lam, 1, n, m, T, N, 1,
                                     cost=(torch.ones(T + 1, dtype=torch.float64, device="cuda"), np.ones(n), np.ones(m)))
+    # a forced family that does not take it is refused as well (the workgroup kernel for a shape the matrix cores take)
+    n, m = 12, 4
+    stack = S.backward_inputs(n, m, T, N, seed=1)
+    d = {k: L.to_device(stack[k], 0) for k in ("cx", "cu", "A", "B")}
+    with pytest.raises(TrajoptError):
+        backward.ilqr_backward_pass(None, d["cx"], None, d["cu"], None, d["A"], d["B"], lam, 1, n, m, T, N, 0, kernel=1,
+                                    cost=(torch.ones(T + 1, dtype=torch.float64, device="cuda"), np.ones(n), np.ones(m)))
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("n,m,T,N", [(12, 4, 40, 9), (5, 2, 33, 7), (8, 3, 21, 5), (11, 2, 18, 4), (4, 1, 30, 6)])
+@pytest.mark.parametrize("reg", [1, 2])
+@pytest.mark.parametrize("full", [True, False])
+def test_structured_cost_on_the_matrix_core_kernel_matches_dense_oracle(oracle, layout, n, m, T, N, reg, full):
+    """The wave-per-problem matrix-core kernel (C4's family, forced: kernel = 2) with the structured cost, both layouts,
+    both regularisation modes (reg = 1 is a compile-time instantiation of its own), full and gains-only outputs, a zero
+    weight (`if a:` drops the state cost) - against the oracle on the equivalent dense arrays."""
+    import torch
+    from trajopt_amd import backward, layout as L, synthetic as S
+    rng = np.random.default_rng(100 * n + m)
+    stack = S.backward_inputs(n, m, T, N, seed=700 + n)
+    w = np.abs(rng.standard_normal(T + 1)) + 0.1
+    w[T // 2] = 0.0
+    gxx, guu = np.abs(rng.standard_normal(n)) + 0.5, np.abs(rng.standard_normal(m)) + 0.05
+    Cxx = np.zeros((N, n, n, T + 1)); Cuu = np.zeros((N, m, m, T + 1)); Cxu = np.zeros((N, n, m, T + 1))
+    Cxx[:, np.arange(n), np.arange(n), :] = gxx[None, :, None] * w[None, None, :]
+    Cuu[:, np.arange(m), np.arange(m), :] = guu[None, :, None]
+    stack = dict(stack, Cxx=Cxx, Cuu=Cuu, Cxu=Cxu)
+    d = {k: L.to_device(stack[k], layout) for k in ("cx", "cu", "A", "B")}
+    lam = torch.full((N,), 0.7, dtype=torch.float64, device="cuda")
+    o = backward.ilqr_backward_pass(None, d["cx"], None, d["cu"], None, d["A"], d["B"], lam, reg, n, m, T, N, layout,
+                                    kernel=2, full=full, cost=(torch.as_tensor(w, device="cuda"), gxx, guu))
+    torch.cuda.synchronize()
+    assert not (o["diverge"].cpu().numpy() >= 0).any()
+    keys = OUT if full else ("dV", "K", "kff")
+    for p in range(N):
+        q = S.problem(stack, p)
+        ref, failed = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], 0.7, reg, n, m, T)
+        assert not failed
+        for k, r in zip(OUT, ref[:10]):
+            if k in keys:
+                assert_close(L.from_device(o[k], layout)[p], r, "%s[p=%d]" % (k, p))
 
 
 def test_a_forced_kernel_family_without_the_shape_is_refused():

@@ -545,3 +545,27 @@ def test_two_pass_line_search_is_bitwise_the_one_launch_line_search_on_every_mod
     p = int(np.argmax([len(t) for t in a["traces"]]))
     r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=5)
     assert abs(a["last_return"][p] - r["last_return"]) <= 1e-9 * abs(r["last_return"])
+
+
+def test_mpc_with_device_drawn_kff_noise_is_reproducible_and_stays_on_the_device(oracle):
+    """the per-solve initial feed-forward noise (ilqr.py:70) comes from a device generator by default -
+    same seed, same run, bit for bit; a different seed differs; and the draw has the reference's scale (1e-4)."""
+    import torch
+    from trajopt_amd import envs
+    from trajopt_amd.mpc import BatchedMPC
+    N, horizon, steps = 64, 24, 3
+    rng = np.random.Generator(np.random.PCG64(3))
+    x0 = np.array([0., np.pi, 0., 0.])[None] + 1e-2 * rng.standard_normal((N, 4))
+    runs = []
+    for seed in (5, 5, 6):
+        mpc = BatchedMPC(envs.make("cartpole", dt=0.02), horizon, x0, nb_iter=3, action_penalty=np.array([1e-5]))
+        runs.append(mpc.run(steps, seed=seed))
+    assert np.array_equal(runs[0]["action"], runs[1]["action"]) and np.array_equal(runs[0]["state"], runs[1]["state"])
+    assert not np.array_equal(runs[0]["cost"], runs[2]["cost"])   # (the first actions saturate at -umax whatever the noise)
+    assert np.all(np.isfinite(runs[0]["state"]))
+    s = mpc.solver
+    g = torch.Generator(device=s.device)
+    g.manual_seed(1)
+    s.reset(torch.as_tensor(x0, device=s.device), generator=g)
+    k = s.host("kff")
+    assert k.shape == (N, 1, horizon) and abs(k.std() / 1e-4 - 1.0) < 0.1 and abs(k.mean()) < 2e-5

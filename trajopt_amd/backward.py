@@ -59,6 +59,8 @@ def ilqr_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, dm_state, dm_act
         io.Cxx, io.Cuu, io.Cxu = map(dptr, (Cxx, Cuu, Cxu))
     else:
         w, gxx, guu = cost
+        if n > _lib.MAX_STATE or m > _lib.MAX_ACT:
+            raise _lib.TrajoptError("the structured cost holds at most %d state and %d action weights" % (_lib.MAX_STATE, _lib.MAX_ACT))
         if w.dtype != torch.float64 or not w.is_cuda or not w.is_contiguous() or w.numel() != T + 1:
             raise ValueError("cost weighting must be a contiguous CUDA float64 tensor with %d elements" % (T + 1))
         io.cost_w = dptr(w)

@@ -114,10 +114,13 @@ int trajopt_device_count(void) {
 }
 
 int trajopt_backward_supports_structured_cost(int n, int m, int T, int64_t NP, int layout) {
-    // exactly the shapes the lane-per-problem and the four-problems-per-wave kernels take (see the dispatcher below)
+    // the family the dispatcher below picks by itself for this shape must take it: lane-per-problem, four-problems-
+    // per-wave, column-per-lane (struct-of-arrays, dx <= 6) or wave-per-problem on the matrix cores (dx + du <= 16,
+    // du <= 4, either layout); the workgroup kernel does not
     if (n <= 0 || m <= 0 || T <= 0 || NP <= 0) return 0;
-    if (!(layout == TRAJOPT_LAYOUT_PROBLEM_MINOR || NP == 1) || !tpp_offsets_fit(n, NP)) return 0;
-    return ((m == 1 && (n == 2 || n == 3 || n == 4 || n == 6)) || (n == 4 && m == 2)) ? 1 : 0;
+    if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return 0;
+    const int fam = backward_kernel_family(n, m, T, NP, layout, TRAJOPT_KERNEL_AUTO);
+    return (fam == TRAJOPT_KERNEL_LANE || fam == TRAJOPT_KERNEL_MFMA4 || fam == TRAJOPT_KERNEL_COLUMNS || fam == TRAJOPT_KERNEL_MFMA16) ? 1 : 0;
 }
 
 int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg, int n, int m, int T, int64_t NP,
@@ -133,7 +136,7 @@ int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg,
     trajopt_lambda_schedule_t s = sched ? *sched : trajopt_lambda_schedule_t{1e-6, 1e6, 1.6};
     hipStream_t st = as_stream(stream);
     const int fam = backward_kernel_family(n, m, T, NP, layout, io->kernel);
-    if (fam < 0 || (io->cost_w && fam != TRAJOPT_KERNEL_LANE && fam != TRAJOPT_KERNEL_MFMA4 && fam != TRAJOPT_KERNEL_COLUMNS)) return TRAJOPT_ERR_UNSUPPORTED;
+    if (fam < 0 || (io->cost_w && fam != TRAJOPT_KERNEL_LANE && fam != TRAJOPT_KERNEL_MFMA4 && fam != TRAJOPT_KERNEL_COLUMNS && fam != TRAJOPT_KERNEL_MFMA16)) return TRAJOPT_ERR_UNSUPPORTED;
     bool handled = false;
     int rc = TRAJOPT_OK;
     switch (fam) {

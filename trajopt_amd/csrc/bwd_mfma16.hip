@@ -77,7 +77,20 @@ struct Slot {
 
 constexpr int kLdQ = 17;  // leading dimension of the 16 x 16 LDS tiles (odd: conflict-free rows and columns)
 
-template <int S, int M, bool MINOR, bool FULL>
+// One wave is the whole workgroup: its LDS accesses execute in program order, so a round trip through LDS needs no
+// s_barrier and, above all, no wait for the global loads in flight (hipcc's __syncthreads() drains vmcnt as well, i.e.
+// the prefetch of the next step) - only the compiler must keep the order.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// R1: reg == 1 is known at compile time (lambda I on Quu, util.cpp:141-143: the driver's and the reference's default) -
+// the reg == 2 machinery (F'F, the sR tile, a branch per element read) then does not exist in the kernel; the other
+// instantiation takes any reg at run time.
+// SC: structured cost (trajopt_backward_io_t::cost_w): Cxx_t = w[t] diag(gxx), Cuu = diag(guu), Cxu = 0 are formed in
+// registers instead of being read - 1664 of the 3328 bytes a quadrotor step reads.
+template <int S, int M, bool MINOR, bool FULL, bool R1, bool SC>
 __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
     __shared__ double sQ[16 * kLdQ];  // Q (later the unsymmetrised V), element (row, col) at row + kLdQ * col
     __shared__ double sq[16];         // [qx; qu], later v
@@ -90,6 +103,22 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
     const bool live = c < n;
     const bool want_gn = io.uref != nullptr && io.g_norm != nullptr;
+    const int reg = R1 ? 1 : a.reg;
+    // structured cost: this lane's entries of the (diagonal) tile C = diag(w gxx, guu) in D layout, rows g + 4 r
+    double scx[4], scu[4];
+    if constexpr (SC) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = g + 4 * r;
+            double gx = 0.0, gu = 0.0;
+#pragma unroll
+            for (int i = 0; i < TRAJOPT_ENV_MAX_STATE; ++i) gx = (row == c && row == i && i < n) ? io.cost_gxx[i] : gx;
+#pragma unroll
+            for (int j = 0; j < TRAJOPT_ENV_MAX_ACT; ++j) gu = (row == c && row == n + j && j < M) ? io.cost_guu[j] : gu;
+            scx[r] = gx;
+            scu[r] = gu;
+        }
+    }
     const int kmul = io.out_bank ? TRAJOPT_GAIN_BANKS : 1, bank = gains_bank(io.out_bank, p);
     // F in B layout: Fb[s] = F[4s + g][c] is one slot walked with a fixed row offset of 4 rows per k-step
     const ptrdiff_t row4 = MINOR ? (ptrdiff_t)(4 * NP) : 4;
@@ -107,6 +136,7 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
         Slot sF, sC[4], sc;
         if (c < n) sF.set<MINOR>(io.A, nn, T, T - 1, g + (size_t)n * c, p, NP, true);
         else sF.set<MINOR>(io.B, nm, T, T - 1, g + (size_t)n * (c < d ? c - n : 0), p, NP, c < d);
+        if constexpr (!SC) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {  // C in D layout: C[g + 4r][c], C = [Cxx Cxu; Cxu' Cuu]
             const int row = g + 4 * r;
@@ -118,6 +148,7 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
                 if (c < n) sC[r].set<MINOR>(io.Cxu, nm, T + 1, T - 1, c + (size_t)n * i, p, NP, row < d);
                 else sC[r].set<MINOR>(io.Cuu, mm, T + 1, T - 1, i + (size_t)m * (c < d ? c - n : 0), p, NP, row < d && c < d);
             }
+        }
         }
         if (c < n) sc.set<MINOR>(io.cx, n, T + 1, T - 1, c, p, NP, true);
         else sc.set<MINOR>(io.cu, m, T + 1, T - 1, c < d ? c - n : 0, p, NP, c < d);
@@ -134,7 +165,10 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
         for (int r = 0; r < 4; ++r) {
             const int row = g + 4 * r;
             double xt = 0.0;
-            if (row < n && live) {
+            if constexpr (SC) {
+                xt = io.cost_w[T] * scx[r];
+                if (FULL && io.V && row < n && live) io.V[at<MINOR>(nn, T + 1, T, row + (size_t)n * c, p, NP)] = xt;
+            } else if (row < n && live) {
                 xt = io.Cxx[at<MINOR>(nn, T + 1, T, c + (size_t)n * row, p, NP)];
                 if (FULL && io.V) io.V[at<MINOR>(nn, T + 1, T, row + (size_t)n * c, p, NP)] =
                     io.Cxx[at<MINOR>(nn, T + 1, T, row + (size_t)n * c, p, NP)];
@@ -152,22 +186,32 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
         d4 Cd, Cn;
 #pragma unroll
         for (int s = 0; s < S; ++s) { const double x = sF.ptr[frow[s] ? s * row4 : 0]; Fb[s] = frow[s] ? x : 0.0; }
+        auto cost_tile = [&](int t, d4& C) {
+            if constexpr (SC) {
+                const double wt = io.cost_w[t];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cd[r] = sC[r].get();
+                for (int r = 0; r < 4; ++r) C[r] = fma(wt, scx[r], scu[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[r] = sC[r].get();
+            }
+        };
+        cost_tile(T - 1, Cd);
         qc = sc.get();
 
         for (int t = T - 1; t >= 0; --t) {
             // unconditional prefetch of step t - 1 (the slots stop walking at step 0: a harmless re-load)
             if (t >= 1) {
                 sF.back();
+                if constexpr (!SC) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sC[r].back();
+                    for (int r = 0; r < 4; ++r) sC[r].back();
+                }
                 sc.back();
             }
 #pragma unroll
             for (int s = 0; s < S; ++s) { const double x = sF.ptr[frow[s] ? s * row4 : 0]; Fn[s] = frow[s] ? x : 0.0; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cn[r] = sC[r].get();
+            cost_tile(t >= 1 ? t - 1 : 0, Cn);
             qn = sc.get();
             double ur = 0.0;
             if (want_gn && g == 0 && c < m) ur = io.uref[at<MINOR>(m, T, t, c, p, NP)];
@@ -180,7 +224,7 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
 #pragma unroll
             for (int s = 0; s < S; ++s) Qd = __builtin_amdgcn_mfma_f64_16x16x4f64(Fb[s], Pd[s], Qd, 0, 0, 0);
             d4 Rd = {0.0, 0.0, 0.0, 0.0};  // F' F, rows n.. give B'A and B'B for reg == 2 (util.cpp:135-141)
-            if (a.reg == 2) {
+            if (reg == 2) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) Rd = __builtin_amdgcn_mfma_f64_16x16x4f64(Fb[s], Fb[s], Rd, 0, 0, 0);
             }
@@ -190,11 +234,11 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
             for (int s = 0; s < S; ++s) qv = fma(Fb[s], vrow[s], qv);
             qv = qc + xor_sum(qv);
 
-            __syncthreads();  // previous step's readers of sQ / sq are done
+            wave_lds_fence();  // previous step's readers of sQ / sq are done
 #pragma unroll
             for (int r = 0; r < 4; ++r) sQ[(g + 4 * r) + kLdQ * c] = Qd[r];
             if (g == 0) sq[c] = qv;
-            if (a.reg == 2) {  // Q_reg[n + i][:] = Q[n + i][:] + lam (F'F)[n + i][:]
+            if (reg == 2) {  // Q_reg[n + i][:] = Q[n + i][:] + lam (F'F)[n + i][:]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = g + 4 * r;
@@ -223,7 +267,7 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
                     else if (c < d) { if (io.qu) io.qu[at<MINOR>(m, T, t, c - n, p, NP)] = qv; }
                 }
             }
-            __syncthreads();
+            wave_lds_fence();
 
             // ---- gains -------------------------------------------------------------------------------------------
             // Every lane factors the same m x m matrix and solves for kff; lane (c, g) solves column c of K.  What
@@ -238,8 +282,8 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
 #pragma unroll
                     for (int i = 0; i < M; ++i) {
                         double xr = sQ[(n + i) + kLdQ * (n + j)];
-                        if (a.reg == 2) xr += sR[i + 4 * (n + j)];
-                        else if (a.reg == 1 && i == j) xr += lam;
+                        if (reg == 2) xr += sR[i + 4 * (n + j)];
+                        else if (reg == 1 && i == j) xr += lam;
                         Quu_r[i + M * j] = xr;
                     }
                 if (!sympd_ldl<M>(Quu_r, L, id)) {  // wave-uniform
@@ -251,7 +295,7 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
             for (int i = 0; i < M; ++i) {
                 qu[i] = sq[n + i];
                 Quxc[i] = sQ[cc + kLdQ * (n + i)];  // Qux[i][cc] = Qxu[cc][i]
-                Kc[i] = Quxc[i] + (a.reg == 2 ? sR[i + 4 * cc] : 0.0);
+                Kc[i] = Quxc[i] + (reg == 2 ? sR[i + 4 * cc] : 0.0);
             }
             double kf[M];
 #pragma unroll
@@ -289,11 +333,11 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
             if (c == 0 && g < M) io.kff[at_gain<MINOR>(m, T, t, g, p, NP, kmul, bank)] = kfg;
             if (want_gn && g == 0 && c < m) gmax = nanmax(gmax, fabs(pick<M>(kf, c)) / (fabs(ur) + 1.0));
 
-            __syncthreads();  // gains have read sQ / sq
+            wave_lds_fence();  // gains have read sQ / sq
 #pragma unroll
             for (int r = 0; r < 4; ++r) sQ[(g + 4 * r) + kLdQ * c] = Wd[r];
             if (g == 0) sq[c] = live ? vn : 0.0;
-            __syncthreads();
+            wave_lds_fence();
             // symmetrise (util.cpp:161) and clear the padding so that it stays finite
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -318,7 +362,7 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
         // exit every wave reaches: also when lam can no longer grow (max_lmbda = inf, NaN inputs) - the
         // reference's `while not backpass_done` would spin forever there (ilqr.py:162-173)
         if (!(lam <= a.sched.max_lmbda) || !(lam < 1e300) || ++retries >= kMaxLambdaRetries) break;
-        __syncthreads();
+        wave_lds_fence();
     }
 
     if (lane == 0) {
@@ -331,9 +375,9 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
         }
     }
     if (want_gn) {
-        __syncthreads();
+        wave_lds_fence();
         if (g == 0 && c < m) sq[c] = gmax;
-        __syncthreads();
+        wave_lds_fence();
         if (lane == 0) {
             double s = 0.0;
             for (int j = 0; j < m; ++j) s += sq[j];
@@ -347,10 +391,19 @@ static int launch_sm(const Mf16Args& a, int layout, hipStream_t st) {
     const dim3 grid((unsigned)a.NP), block(64);
     const bool full = a.io.Qxx || a.io.Qux || a.io.Quu || a.io.qx || a.io.qu || a.io.V || a.io.v;
     const bool minor = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR;
-    if (minor && full) hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, true, true>), grid, block, 0, st, a);
-    else if (minor) hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, true, false>), grid, block, 0, st, a);
-    else if (full) hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, false, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, false, false>), grid, block, 0, st, a);
+    const bool r1 = a.reg == 1, sc = a.io.cost_w != nullptr;
+#define TJ_GO(MI, FU) \
+    do { \
+        if (r1 && sc) hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, MI, FU, true, true>), grid, block, 0, st, a); \
+        else if (r1) hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, MI, FU, true, false>), grid, block, 0, st, a); \
+        else if (sc) hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, MI, FU, false, true>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, MI, FU, false, false>), grid, block, 0, st, a); \
+    } while (0)
+    if (minor && full) TJ_GO(true, true);
+    else if (minor) TJ_GO(true, false);
+    else if (full) TJ_GO(false, true);
+    else TJ_GO(false, false);
+#undef TJ_GO
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
 }

@@ -32,6 +32,12 @@ struct RolloutArgs {
     // goes to plane first_plane + ai, the lanes of stopped problems to junk_plane.
     int first_plane, junk_plane;
     int xcd_tiles;   // 1: workgroup -> (tile of 64 problems, alpha) mapping that keeps a tile's alphas on one XCD
+    // 1: thread index = problem * nA + alpha (the alphas of a problem in neighbouring lanes) instead of alpha * NP +
+    // problem.  For PROBLEM_MAJOR gains (dx > 6): a lane reads its problem's K_t as dx du consecutive doubles, so 64
+    // different problems in a wave are 64 x 6 cache lines per step (quadrotor: 48 KB, more than the CU's vector cache
+    // holds - every one of the 52 loads of a step went to L2 for 64 lines); with the alphas of a problem side by
+    // side a wave touches an eighth of that and the other lanes hit the same lines.
+    int alpha_minor;
     // ... and the gains K / kff hold TRAJOPT_GAIN_BANKS banks, of which problem p reads bank out_bank[p] (layout:
     // trajopt_backward_io_t::out_bank); NULL: plain arrays
     const int32_t* out_bank;
@@ -137,6 +143,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         idle = idx >= cnt * (size_t)(a.nb_alphas - a.alpha_begin);
         p = idle ? 0 : (size_t)a.plist[idx % (cnt ? cnt : 1)];
         ai = idle ? a.alpha_begin : a.alpha_begin + (int)(idx / (cnt ? cnt : 1));
+    } else if (a.alpha_minor) {
+        const size_t nA = (size_t)(a.nb_alphas - a.alpha_begin);
+        idle = idx >= NP * nA;
+        p = idle ? 0 : idx / nA;
+        ai = idle ? a.alpha_begin : a.alpha_begin + (int)(idx % nA);
     } else {
         idle = idx >= NP * (size_t)(a.nb_alphas - a.alpha_begin);
         p = idle ? 0 : idx % NP;
@@ -682,6 +693,8 @@ int launch_rollout(const trajopt_env_t* env, int T, int64_t NP, int layout, cons
     if (L.cost_only && (L.a.sel || !rollout_cost_only_supported(env, T, NP, k_layout))) return TRAJOPT_ERR_UNSUPPORTED;
     L.a.xcd_tiles = (planes && !L.a.sel && (double)NP * (alpha_end - alpha_begin) > 65536.0) ? 1 : 0;
     L.tb = planes != nullptr && !L.cost_only;
+    L.a.alpha_minor = (planes && !L.a.sel && !plist && !L.a.xcd_tiles && layout == TRAJOPT_LAYOUT_PROBLEM_MINOR &&
+                       k_layout == TRAJOPT_LAYOUT_PROBLEM_MAJOR) ? 1 : 0;
     nb_alphas = alpha_end;  // the kernel runs alphas [alpha_begin, alpha_end)
     L.a.env = *env;
     L.a.x0 = x0; L.a.K = K; L.a.kff = kff; L.a.xref = xref; L.a.uref = uref; L.a.weighting = weighting;

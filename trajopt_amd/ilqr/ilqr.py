@@ -158,11 +158,14 @@ class BatchedILQR:
         self._trace_bound = 0
         self._lmbda0, self._dlmbda0 = float(lmbda), float(dlmbda)
 
-    def reset(self, init_state, kff_init=None):
+    def reset(self, init_state, kff_init=None, generator=None):
         """Re-arm the solver for new initial states without reallocating anything: the state a FRESH
         iLQR(env, nb_steps, init_state) would have (ilqr.py:59-70,87) - the reference's MPC loops build a new
         solver at every control step (examples/ilqr/mpc/pendulum.py:22-27).  init_state: (N, dm_state) array or
-        device tensor; kff_init as in the constructor."""
+        device tensor; kff_init as in the constructor.  generator: a torch.Generator of this device - with kff_init
+        None the initial feed-forward 1e-4 * randn (ilqr.py:70) is then drawn ON THE DEVICE, straight into the gains
+        layout (nothing crosses PCIe: with a device init_state the whole reset is device work); without it the draw comes
+        from np.random as in the reference, 8 N m T bytes generated on the host and uploaded."""
         import torch
         N, n, m, T = self.nb_problems, self.dm_state, self.dm_act, self.nb_steps
         if torch.is_tensor(init_state):
@@ -174,9 +177,14 @@ class BatchedILQR:
         self.xref[0] = self.x0
         self.uref.zero_()
         self.K.zero_()
-        if kff_init is None:
+        if kff_init is None and generator is not None:
+            self.kff.normal_(generator=generator).mul_(1e-4)   # iid: the layout does not matter
+            kff_init = self.kff
+        elif kff_init is None:
             kff_init = 1e-4 * np.random.randn(N, m, T)
-        if torch.is_tensor(kff_init):   # logical (N, m, T), as the NumPy branch: permuted into the gains layout
+        if kff_init is self.kff:
+            pass
+        elif torch.is_tensor(kff_init):   # logical (N, m, T), as the NumPy branch: permuted into the gains layout
             k = kff_init.detach().to(device=self.device, dtype=torch.float64).reshape(N, m, T)
             self.kff.copy_(k.permute(2, 1, 0) if self.gains_layout == LAYOUT_PROBLEM_MINOR else k.permute(0, 2, 1))
         else:

@@ -46,10 +46,13 @@ class BatchedMPC:
                                                        _lib.dptr(xn), None, _lib.stream_ptr()))
         return xn
 
-    def run(self, nb_steps, process_noise=None, kff_inits=None, seed=1337):
+    def run(self, nb_steps, process_noise=None, kff_inits=None, seed=1337, kff_rng="device", to_host=True):
         """-> dict(state (N, n, nb_steps + 1), action (N, m, nb_steps), cost (N, nb_steps): last accepted return of
-        each horizon solve).  kff_inits: optional (nb_steps, N, m, horizon) initial feed-forward noise per solve
-        (default: 1e-4 * randn from np.random, as a fresh reference solver draws, ilqr.py:70)."""
+        each horizon solve).  kff_inits: optional (nb_steps, N, m, horizon) initial feed-forward noise per solve.
+        Without it every solve draws 1e-4 * randn as a fresh reference solver does (ilqr.py:70): kff_rng = "device"
+        (default) from a torch generator ON THE GPU (seeded with `seed`; no host work, no upload - at 65 536 cartpoles x
+        T = 500 the host draw is 262 MB per control step), kff_rng = "numpy" from np.random as the reference (to
+        reproduce a reference run's stream).  to_host=False returns the device tensors (T-major, PROBLEM_MINOR)."""
         import torch
         s = self.solver
         N, n, m = self.nb_problems, self.dm_state, self.dm_act
@@ -58,6 +61,11 @@ class BatchedMPC:
         action = torch.empty((nb_steps, m, N), dtype=torch.float64, device=dev)
         cost = torch.empty((nb_steps, N), dtype=torch.float64, device=dev)
         state[0] = torch.as_tensor(self._x0, device=dev).t()
+        assert kff_rng in ("device", "numpy")
+        kgen = None
+        if kff_inits is None and kff_rng == "device":
+            kgen = torch.Generator(device=dev)
+            kgen.manual_seed(seed + 977)
         gen = None
         chol = None
         if isinstance(process_noise, str):
@@ -68,7 +76,7 @@ class BatchedMPC:
         elif process_noise is not None:
             process_noise = torch.as_tensor(np.asarray(process_noise, dtype=np.float64), device=dev)  # (N, n, steps)
         for t in range(nb_steps):
-            s.reset(state[t].t(), None if kff_inits is None else kff_inits[t])
+            s.reset(state[t].t(), None if kff_inits is None else kff_inits[t], generator=kgen)
             s.init_rollout()
             s.iterate(self.nb_iter)
             action[t] = s.uref[0]
@@ -80,5 +88,7 @@ class BatchedMPC:
                 xn = xn + process_noise[:, :, t].t()
             state[t + 1] = xn
         torch.cuda.synchronize(dev)
+        if not to_host:
+            return dict(state=state, action=action, cost=cost)
         return dict(state=state.permute(2, 1, 0).cpu().numpy(), action=action.permute(2, 1, 0).cpu().numpy(),
                     cost=cost.t().cpu().numpy())
