@@ -561,11 +561,17 @@ def test_mpc_with_device_drawn_kff_noise_is_reproducible_and_stays_on_the_device
         mpc = BatchedMPC(envs.make("cartpole", dt=0.02), horizon, x0, nb_iter=3, action_penalty=np.array([1e-5]))
         runs.append(mpc.run(steps, seed=seed))
     assert np.array_equal(runs[0]["action"], runs[1]["action"]) and np.array_equal(runs[0]["state"], runs[1]["state"])
-    assert not np.array_equal(runs[0]["cost"], runs[2]["cost"])   # (the first actions saturate at -umax whatever the noise)
+    # (the third run only has to work: these cartpoles saturate at -umax whatever the 1e-4 noise, so its results may coincide)
     assert np.all(np.isfinite(runs[0]["state"]))
     s = mpc.solver
     g = torch.Generator(device=s.device)
     g.manual_seed(1)
     s.reset(torch.as_tensor(x0, device=s.device), generator=g)
-    k = s.host("kff")
+    k = s.host("kff").copy()
     assert k.shape == (N, 1, horizon) and abs(k.std() / 1e-4 - 1.0) < 0.1 and abs(k.mean()) < 2e-5
+    g.manual_seed(2)
+    s.reset(torch.as_tensor(x0, device=s.device), generator=g)
+    assert not np.array_equal(k, s.host("kff"))
+    g.manual_seed(1)
+    s.reset(torch.as_tensor(x0, device=s.device), generator=g)
+    assert np.array_equal(k, s.host("kff"))

@@ -38,19 +38,24 @@ def ilqr_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, dm_state, dm_act
     _chk(lmbda, N, "lmbda")
     dev = A.device
     o = {} if out is None else out
-    o.setdefault("K", empty((N, m, n, T), layout, dev, zero=True))
-    o.setdefault("kff", empty((N, m, T), layout, dev, zero=True))
-    o.setdefault("dV", empty((N, 2), layout, dev, zero=True))
+
+    def need(key, *logical):   # allocated (zero-filled) only when the caller's `out` does not hold it yet
+        if key not in o:
+            o[key] = empty((N,) + logical, layout, dev, zero=True)
+
+    need("K", m, n, T)
+    need("kff", m, T)
+    need("dV", 2)
     if "diverge" not in o:
         o["diverge"] = torch.empty(N, dtype=torch.int32, device=dev)
     if full:
-        o.setdefault("Qxx", empty((N, n, n, T), layout, dev, zero=True))
-        o.setdefault("Qux", empty((N, m, n, T), layout, dev, zero=True))
-        o.setdefault("Quu", empty((N, m, m, T), layout, dev, zero=True))
-        o.setdefault("qx", empty((N, n, T), layout, dev, zero=True))
-        o.setdefault("qu", empty((N, m, T), layout, dev, zero=True))
-        o.setdefault("V", empty((N, n, n, T + 1), layout, dev, zero=True))
-        o.setdefault("v", empty((N, n, T + 1), layout, dev, zero=True))
+        need("Qxx", n, n, T)
+        need("Qux", m, n, T)
+        need("Quu", m, m, T)
+        need("qx", n, T)
+        need("qu", m, T)
+        need("V", n, n, T + 1)
+        need("v", n, T + 1)
     if uref is not None and "g_norm" not in o:
         o["g_norm"] = torch.empty(N, dtype=torch.float64, device=dev)
     io = BackwardIO()
@@ -81,9 +86,11 @@ def ilqr_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, lmbda, reg, dm_state, dm_act
 
 
 def riccati_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, c, dm_state, dm_act, nb_steps, nb_problems, layout,
-                          with_status=True):
+                          with_status=True, out=None):
     """TV-LQR sweep of /root/reference/trajopt/riccati/riccati.py:100-126 for a batch -> K, kff, V, v, status.
-    with_status=False passes status = NULL (then at most one such call per GPU at a time: include/trajopt_amd.h)."""
+    with_status=False passes status = NULL (then at most one such call per GPU at a time: include/trajopt_amd.h).
+    out: a dict returned by an earlier call of the same shape - its tensors are written again instead of allocating
+    (and zero-filling) new ones (C5: 42 GB)."""
     import torch
     _lib.require_gpu()
     n, m, T, N = dm_state, dm_act, nb_steps, nb_problems
@@ -92,9 +99,10 @@ def riccati_backward_pass(Cxx, cx, Cuu, cu, Cxu, A, B, c, dm_state, dm_act, nb_s
                        (B, n * m * T, "B"), (c, n * T, "c")):
         _chk(t, cnt * N, nm)
     dev = Cxx.device
-    o = dict(K=empty((N, m, n, T), layout, dev, zero=True), kff=empty((N, m, T), layout, dev, zero=True),
-             V=empty((N, n, n, T + 1), layout, dev, zero=True), v=empty((N, n, T + 1), layout, dev, zero=True),
-             status=torch.zeros(N, dtype=torch.int32, device=dev) if with_status else None)
+    o = out if out is not None else dict(
+        K=empty((N, m, n, T), layout, dev, zero=True), kff=empty((N, m, T), layout, dev, zero=True),
+        V=empty((N, n, n, T + 1), layout, dev, zero=True), v=empty((N, n, T + 1), layout, dev, zero=True),
+        status=torch.zeros(N, dtype=torch.int32, device=dev) if with_status else None)
     check(lib().trajopt_riccati_backward_pass_batched(
         dptr(Cxx), dptr(cx), dptr(Cuu), dptr(cu), dptr(Cxu), dptr(A), dptr(B), dptr(c), n, m, T, C.c_int64(N),
         int(layout), dptr(o["V"]), dptr(o["v"]), dptr(o["K"]), dptr(o["kff"]), dptr(o["status"]), stream_ptr()))

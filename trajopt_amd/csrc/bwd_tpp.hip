@@ -8,6 +8,7 @@
 // per-step temporaries live in VGPRs (all loops unroll).  The time loop is unrolled by two with two
 // named input register sets: the loads of step t-1 are issued before the arithmetic of step t, so
 // HBM latency hides under the ~250 dependent fp64 FMAs of a step.
+#include <cstdlib>
 #include "smallmat.h"
 #include "sys.h"
 
@@ -42,19 +43,29 @@ struct Lane {
     unsigned v8;  // lane * 8
     size_t NP;
 };
+// Cache policy of the streaming loads / stores: 2 = nt (non-temporal).  Every byte of a sweep is touched once, and at the
+// sizes this kernel is chosen for nothing of it fits a cache; measured on 65 536 problems, dense inputs (scripts/debug/
+// tpp_nt_sweep.sh): cartpole gains-only 4.81 -> 4.99 TB/s, full 4.74 -> 4.78; double cartpole 3.89 -> 4.08 / 4.35 -> 4.58
+// (nt on the loads alone or the stores alone gives about half of that each).
+#ifndef TPP_LD_AUX
+#define TPP_LD_AUX 2
+#endif
+#ifndef TPP_ST_AUX
+#define TPP_ST_AUX 2
+#endif
 template <int R>
 __device__ __forceinline__ void load_vec(double (&x)[R], const double* ubase, const Lane& ln) {
     const __amdgpu_buffer_rsrc_t r = mk_rsrc(ubase);
 #pragma unroll
     for (int e = 0; e < R; ++e)
-        x[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, ln.v8, (unsigned)(e * ln.NP * 8), 0));
+        x[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, ln.v8, (unsigned)(e * ln.NP * 8), TPP_LD_AUX));
 }
 template <int R>
 __device__ __forceinline__ void store_vec(double* ubase, const Lane& ln, const double (&x)[R]) {
     const __amdgpu_buffer_rsrc_t r = mk_rsrc(ubase);
 #pragma unroll
     for (int e = 0; e < R; ++e)
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x[e]), r, ln.v8, (unsigned)(e * ln.NP * 8), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x[e]), r, ln.v8, (unsigned)(e * ln.NP * 8), TPP_ST_AUX);
 }
 
 // ubase(arr, E, t): wave-uniform pointer to element 0 of step t for the wave's first problem.
@@ -312,7 +323,11 @@ __device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N *
     return true;
 }
 
-template <int N, int M, bool FULL, bool GN, bool SC>
+// DEPTH: how many steps ahead the inputs are fetched.  One (two register sets) hides the HBM latency under a step's
+// arithmetic while several waves share a SIMD; a batch of 16k - 100k problems is one or two waves per SIMD, each of
+// which then waits ~5 us per step for 23 KB (dense cartpole) with 0.7 us of arithmetic to do - two steps ahead (three
+// register sets, the loop unrolled by three) doubles the bytes every wave keeps in flight.
+template <int N, int M, bool FULL, bool GN, bool SC, int DEPTH>
 __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
     const size_t p0 = (size_t)blockIdx.x * a.lpw;  // wave-uniform: first problem of this wave
     const unsigned lane = threadIdx.x;
@@ -361,6 +376,22 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
         StepIn<N, M> s0, s1;
         int t = T - 1;
         load_step<N, M, GN, SC>(s0, a, p0, off, t);
+        if constexpr (DEPTH == 2) {
+            StepIn<N, M> s2;
+            auto clamp = [](int x) { return x >= 0 ? x : 0; };
+            load_step<N, M, GN, SC>(s1, a, p0, off, clamp(t - 1));
+            while (t >= 0) {
+                load_step<N, M, GN, SC>(s2, a, p0, off, clamp(t - 2));
+                if (!bwd_step<N, M, FULL, GN>(s0, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) { div = t; break; }
+                if (--t < 0) break;
+                load_step<N, M, GN, SC>(s0, a, p0, off, clamp(t - 2));
+                if (!bwd_step<N, M, FULL, GN>(s1, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) { div = t; break; }
+                if (--t < 0) break;
+                load_step<N, M, GN, SC>(s1, a, p0, off, clamp(t - 2));
+                if (!bwd_step<N, M, FULL, GN>(s2, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) { div = t; break; }
+                --t;
+            }
+        } else
         while (t >= 0) {
             load_step<N, M, GN, SC>(s1, a, p0, off, t >= 1 ? t - 1 : 0);
             if (!bwd_step<N, M, FULL, GN>(s0, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) {
@@ -616,18 +647,36 @@ static int pick_lpw(size_t) {
     return 64;
 }
 
+constexpr size_t kDepth2MinProblems = 12288, kDepth2MaxProblems = 262144;   // (measured: see DESIGN.md section 3)
+
 template <int N, int M, bool SC>
 static int launch_nms(const TppArgs& a, hipStream_t st) {
     const bool full = a.io.Qxx || a.io.Qux || a.io.Quu || a.io.qx || a.io.qu || a.io.V || a.io.v;
     const bool gn = a.io.uref != nullptr && a.io.g_norm != nullptr;
     const dim3 block(64);
     const dim3 grid((unsigned)((a.NP + a.lpw - 1) / a.lpw));
+    // two steps ahead where three register sets fit (dx <= 4) and a SIMD holds few waves of this launch
+    int depth = (N * N + N * M <= 24 && a.NP >= kDepth2MinProblems && a.NP <= kDepth2MaxProblems) ? 2 : 1;
+    if (const char* e = getenv("TRAJOPT_TPP_DEPTH")) { if (N * N + N * M <= 24) depth = atoi(e) == 2 ? 2 : 1; }
+    if constexpr (N * N + N * M <= 24) {
+        if (depth == 2) {
+            if (full) {
+                if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, true, SC, 2>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, false, SC, 2>), grid, block, 0, st, a);
+            } else {
+                if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, true, SC, 2>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, false, SC, 2>), grid, block, 0, st, a);
+            }
+            TRAJOPT_HIP_CHECK(hipGetLastError());
+            return TRAJOPT_OK;
+        }
+    }
     if (full) {
-        if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, true, SC>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, false, SC>), grid, block, 0, st, a);
+        if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, true, SC, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, false, SC, 1>), grid, block, 0, st, a);
     } else {
-        if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, true, SC>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, false, SC>), grid, block, 0, st, a);
+        if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, true, SC, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, false, SC, 1>), grid, block, 0, st, a);
     }
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
