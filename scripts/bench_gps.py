@@ -13,7 +13,10 @@ ARGS = ("Cxx", "cx", "Cuu", "cu", "Cxu", "c0", "A", "B", "c", "sigma_dyn", "alph
 def main():
     out = []
     for (n, m, T, N, full) in [(4, 1, 500, 4096, False), (4, 1, 500, 4096, True), (6, 1, 500, 4096, False),
-                               (4, 2, 500, 4096, False), (2, 1, 100, 65536, False)]:
+                               (4, 2, 500, 4096, False), (2, 1, 100, 65536, False),
+                               # shapes without a lane-per-problem instantiation: the wave-per-problem kernel with run-time
+                               # dimensions (gen_wave.hip) - quad pendulum (8, 4) and a 12 x 4 model
+                               (8, 4, 100, 4096, False), (8, 4, 100, 16384, False), (12, 4, 100, 4096, False)]:
         small = S.gps_inputs(n, m, T, 64, seed=1)
         d = {k: L.to_device(np.tile(small[k], (N // 64,) + (1,) * (small[k].ndim - 1)), 1) for k in ARGS}
         run = lambda: backward.gps_backward_pass(*[d[k] for k in ARGS], n, m, T, N, 1, full=full)
@@ -32,6 +35,7 @@ def main():
         wr = m * n + m + m * m + n * n + n + 1 + (n * n + m * n + m * m + n + m + 1 if full else 0)
         gb = 8.0 * (rd + wr) * T * N / 1e9
         out.append(dict(n=n, m=m, T=T, N=N, full=full, ms=ms, note="includes output allocation + memset",
+                        kernel="lane = problem (gps_tpp.hip)" if (n, m) in ((2, 1), (3, 1), (4, 1), (6, 1), (2, 2), (4, 2)) else "wave = problem, run-time dimensions (gen_wave.hip)",
                         problem_steps_per_s=T * N / ms * 1e3, alg_GB=gb, GBps=gb / ms * 1e3))
         print(json.dumps(out[-1]), flush=True)
     out.append(dual_chain(4, 1, 100, 16384))

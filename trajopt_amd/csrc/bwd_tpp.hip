@@ -647,7 +647,10 @@ static int pick_lpw(size_t) {
     return 64;
 }
 
-constexpr size_t kDepth2MinProblems = 12288, kDepth2MaxProblems = 262144;   // (measured: see DESIGN.md section 3)
+// Measured (scripts/debug/tpp_depth_sweep.sh, dense cartpole shape, gains-only, TB/s one step / two steps ahead): 8192
+// problems 2.73 / 2.86, 16 384 4.42 / 4.36, 65 536 4.42 / 4.38, 131 072 4.27 / 4.25, 262 144 4.64 / 4.74 - the launch is not
+// short of bytes in flight (1024 waves x 46 rows of 512 B), so the deeper prefetch is only taken where it measured ahead.
+constexpr size_t kDepth2MinProblems = 196608, kDepth2MaxProblems = (size_t)1 << 40;
 
 template <int N, int M, bool SC>
 static int launch_nms(const TppArgs& a, hipStream_t st) {
