@@ -9,8 +9,9 @@
 //   Ph1  P(w, :) = V'(w, :) F          wave w needs row strip w of V', which (V' symmetric) is the D-layout image of
 //                                      its own block column: V' never leaves the registers (riccati.py:108-110)
 //   Ph2  Q(:, w) = C(:, w) + F' P(:, w) Qxx block column w, Qux tile w, and a quarter of Quu = Cuu + B'V'B
-//   Ph3  Quu = L D L', K = -Quu^-1 Qux (lane = column), kff = -1/2 Quu^-1 qu                  (riccati.py:118-121)
-//   Ph4  V(:, w) = Qxx(:, w) + K' Qux(w) (= (Qux' K)(:, w) by symmetry), v = qx + 2 Qux' kff   (riccati.py:123-124)
+//   Ph3  block elimination of [Quu | Qux(:, w) | qu] with 4 x 4 pivot blocks, every product a matrix-core instruction:
+//        Y = L^-1 Qux, Z = D^-1 Y (forward), K = -U^-1 Z, kff = -1/2 U^-1 zq (backward)        (riccati.py:118-121)
+//   Ph4  V(:, w) = Qxx(:, w) - Z' Y(:, w) (= Qxx + Qux' K), v = qx - Y' zq (= qx + 2 Qux' kff)  (riccati.py:123-124)
 // F_t is staged in LDS once per step (B operands and, for F', A operands are read from there), P is exchanged
 // through LDS, everything else stays in registers.  The loads of step t-1 are issued at the top of step t.
 //
@@ -94,11 +95,12 @@ constexpr int kLd16 = 17;  // column stride of the 16-row LDS images (Qux, K, Qu
 struct Ric64Lds {
     double F[81 * kLdk];       // [col][k]: cols 0..63 = A, 64..79 = B, 80 = c
     double P[64 * kLdk];       // [col][k]: P = V' A   (the B block column of P stays in registers)
-    double Qux[64 * kLd16];    // Qux[i][j] at i + 17 j
-    double K[64 * kLd16];      // K[i][j]   at i + 17 j
+    double Ko[64 * kLd16];     // the gains K[i][j] at i + 17 j, for the output stores
+    double K[64 * kLd16];      // -Z[i][j] = -(D^-1 L^-1 Qux)[i][j] at i + 17 j: the A operand of the V update
     double QuuP[4][16 * kLd16];  // per-wave partial sums of Quu, (row, col) at row + 17 col
-    double L[4][16 * kLd16];   // per-wave copy of the unit lower factor, L[i][k] at i * 17 + k
-    double w[64], qx[64], qu[16], kff[16];
+    double U[4][16 * kLd16];   // per-wave copy of the unit upper block factor, U[i][j] at i + 17 j
+    double piv[4][16];         // per wave: the 4 x 4 pivot block of the current elimination step, (a, b) at a + 4 b
+    double w[64], qx[64], qu[16], kff[16], zq[16];
     double X[64 * kLdk];       // [col][row]: Cxx_t as it stands in memory, element (row, col) at pk(row) of column col
     double cmax[4];            // per-wave max |Cxx_t| (symmetry check)
     int asym;                  // set when a slice of Cxx fails the symmetry check
@@ -127,6 +129,12 @@ __device__ __forceinline__ double xor_sum16(double x) {  // sum over lanes c, c+
     x += __shfl_xor(x, 16, 64);
     x += __shfl_xor(x, 32, 64);
     return x;
+}
+
+// LDS round trip inside ONE wave (its LDS accesses execute in program order): only the compiler must keep the order
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
@@ -287,6 +295,16 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         return;
     }
 
+    // 0 / 1 masks that place the ten distinct entries of a symmetric 4 x 4 matrix Pi into the matrix-core A operand
+    // A[row c][k-index g] = Pi(c, g), c < 4 (Ph3): entry (a, b), a >= b, goes to the lanes (c, g) = (a, b) and (b, a)
+    double mk[10];
+    {
+        int e = 0;
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2)
+#pragma unroll
+            for (int a2 = b2; a2 < 4; ++a2) mk[e++] = ((c == a2 && g == b2) || (c == b2 && g == a2)) ? 1.0 : 0.0;
+    }
     int bad = -1;
     // nothing of the set-up is in flight when the loop starts: its wait counts then cover the loop's own operations only
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
@@ -416,8 +434,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            S.QuuP[w][(g + 4 * r) + kLd16 * c] = qp[r];
-            S.Qux[(g + 4 * r) + kLd16 * col] = Q[4][r];
+            S.QuuP[w][(g + 4 * r) + kLd16 * c] = qp[r];   // (the Qux tile Q[4] stays in this wave's registers)
         }
         if (tid < 160) {  // [qx; qu] = [cx; cu] + F' w   (riccati.py:112-116)
             const int qc = tid >> 1, half = tid & 1;
@@ -440,71 +457,122 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         __syncthreads();
         RIC_TICK(3)
 
-        // ================= Ph3: Quu = L D L' (every wave, redundantly), K (wave 0), kff (wave 1) ==============
+        // ================= Ph3: block elimination on the matrix cores (every wave: Quu redundantly, its own Qux tile) ===
         {
             const double tol = 1e-13 * fmax(fmax(S.cmax[0], S.cmax[1]), fmax(S.cmax[2], S.cmax[3]));
             if (!(dmax_t <= tol)) S.asym = 1;   // read by everybody behind the next barrier
         }
         stage_F();  // the F image of this step is dead: bring in step t - 1
-        double row[16], invd[16];
+        // Quu = L D L' with 4 x 4 blocks (L unit lower BLOCK triangular, D block diagonal), no pivoting: a non-positive
+        // scalar pivot inside a block flags the problem for the generic kernel.  In the matrix cores' D layout register
+        // r of a 16 x 16 tile holds rows 4 r + g - i.e. ROW BLOCK r - and, for a symmetric tile, that register is at
+        // the same time the B operand "rows of block r" and the A operand "columns of block r".  Step k:
+        //   Pi = (Quu^(k)(blk, blk))^-1            4 x 4, every lane redundantly from a broadcast through LDS
+        //   X' = Pi Quu^(k)(blk, :), Z_k = Pi R(blk, :), zq_k = Pi rq(blk)     one instruction each (Pi zero-padded)
+        //   Quu^(k+1) = Quu^(k) - Quu(:, blk) X',  R -= Quu(:, blk) Z_k,  rq -= Quu(:, blk) zq_k   (rows below the block)
+        // after which R = Y = L^-1 Qux(:, w) and the rows X' are the unit upper factor U = L'.  Ph4 needs only Y and Z;
+        // the gains come from the block back substitution K = -U^-1 Z (three more instructions per tile).
         bool ok = true;
-        {
-            const int r = c;  // lane holds row r of Quu (replicated over g); rows/cols >= m are identity padding
+        d4 Sd, Rq = {0.0, 0.0, 0.0, 0.0}, Zt, Zq4;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double x = 0.0;
+        for (int r = 0; r < 4; ++r) {
+            const int row = g + 4 * r;
+            double x = 0.0;
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww) x += S.QuuP[ww][r + kLd16 * j];
-                row[j] = (r < m && j < m) ? x : (r == j ? 1.0 : 0.0);
+            for (int ww = 0; ww < 4; ++ww) x += S.QuuP[ww][row + kLd16 * c];
+            Sd[r] = (row < m && c < m) ? x : (row == c ? 1.0 : 0.0);   // identity padding beyond du
+            Rq[r] = (c == 0 && row < m) ? S.qu[row] : 0.0;             // qu rides along as column 0 of a tile of its own
+        }
+        d4& R = Q[4];   // this wave's Qux tile, rows i = g + 4 r, column 16 w + c
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // the pivot block to every lane: element (row 4 k + g, column c) is register k of lane (c, g), c in the block
+            if ((c >> 2) == k) S.piv[w][g + 4 * (c & 3)] = Sd[k];
+            wave_fence();
+            double P[16];
+            {
+                const r64_d2* src = reinterpret_cast<const r64_d2*>(S.piv[w]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const r64_d2 x2 = src[e];
+                    P[2 * e] = x2[0];
+                    P[2 * e + 1] = x2[1];
+                }
             }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const double dk = bcast_lane(row[k], k);
-                ok = ok && (dk > 0.0);
-                const double ik = rcp_nr(dk);
-                invd[k] = ik;
-                const double l = (r > k) ? row[k] * ik : 0.0;
-#pragma unroll
-                for (int j = k + 1; j < 16; ++j) row[j] = fma(-l, bcast_lane(row[j], k), row[j]);
-                if (r > k) row[k] = l;
-            }
-            if (g == 0) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) S.L[w][r * kLd16 + k] = row[k];
-            }
+            wave_fence();
+            // P = L4 D4 L4' (unit lower L4), Pi = L4^-T D4^-1 L4^-1; P(a, b) at a + 4 b, lower triangle used
+            const double d0 = P[0];
+            const double i0 = rcp_nr(d0);
+            const double l10 = P[1] * i0, l20 = P[2] * i0, l30 = P[3] * i0;
+            const double d1 = fma(-l10, P[1], P[5]);
+            const double i1 = rcp_nr(d1);
+            const double w21 = fma(-l20, P[1], P[6]), w31 = fma(-l30, P[1], P[7]);
+            const double l21 = w21 * i1, l31 = w31 * i1;
+            const double d2 = fma(-l21, w21, fma(-l20, P[2], P[10]));
+            const double i2 = rcp_nr(d2);
+            const double w32 = fma(-l31, w21, fma(-l30, P[2], P[11]));
+            const double l32 = w32 * i2;
+            const double d3 = fma(-l32, w32, fma(-l31, w31, fma(-l30, P[3], P[15])));
+            const double i3 = rcp_nr(d3);
+            ok = ok && (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
+            // N = L4^-1 (unit lower): rows 1..3
+            const double n10 = -l10, n21 = -l21, n32 = -l32;
+            const double n20 = fma(-l21, n10, -l20), n31 = fma(-l32, n21, -l31);
+            const double n30 = fma(-l32, n20, fma(-l31, n10, -l30));
+            // Pi(a, b) = sum_j N(j, a) i_j N(j, b), j >= max(a, b)
+            const double t1 = n10 * i1, t20 = n20 * i2, t21 = n21 * i2, t30 = n30 * i3, t31 = n31 * i3, t32 = n32 * i3;
+            const double p33 = i3, p32 = t32, p31 = t31, p30 = t30;
+            const double p22 = fma(t32, n32, i2), p21 = fma(t32, n31, t21), p20 = fma(t32, n30, t20);
+            const double p11 = fma(t31, n31, fma(t21, n21, i1)), p10 = fma(t31, n30, fma(t21, n20, t1));
+            const double p00 = fma(t30, n30, fma(t20, n20, fma(t1, n10, i0)));
+            // the A operand "Pi zero-padded to 16 x 4": A[row c][k-index g] = Pi(c, g) for c < 4 - per-lane 0 / 1 masks
+            double Aop = mk[0] * p00;
+            Aop = fma(mk[1], p10, Aop); Aop = fma(mk[2], p20, Aop); Aop = fma(mk[3], p30, Aop);
+            Aop = fma(mk[4], p11, Aop); Aop = fma(mk[5], p21, Aop); Aop = fma(mk[6], p31, Aop);
+            Aop = fma(mk[7], p22, Aop); Aop = fma(mk[8], p32, Aop); Aop = fma(mk[9], p33, Aop);
+            const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+            const d4 Xs = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, Sd[k], zero4, 0, 0, 0);   // rows 0..3: X' = Pi Quu(blk, :)
+            const d4 Zr = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, R[k], zero4, 0, 0, 0);    // rows 0..3: Z_k = Pi Y_k
+            const d4 Zv = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, Rq[k], zero4, 0, 0, 0);   // rows 0..3, column 0: zq_k
+            // columns of the block, rows below it (by symmetry register k again), negated: the rank-4 downdates
+            const double nA = (c >= 4 * (k + 1)) ? -Sd[k] : 0.0;
+            Sd = __builtin_amdgcn_mfma_f64_16x16x4f64(nA, Xs[0], Sd, 0, 0, 0);
+            R = __builtin_amdgcn_mfma_f64_16x16x4f64(nA, Zr[0], R, 0, 0, 0);
+            Rq = __builtin_amdgcn_mfma_f64_16x16x4f64(nA, Zv[0], Rq, 0, 0, 0);
+            Zt[k] = Zr[0];
+            Zq4[k] = Zv[0];
+            S.U[w][(4 * k + g) + kLd16 * c] = Xs[0];           // row 4 k + g of U (its entries right of the block are used)
+            S.K[(4 * k + g) + kLd16 * col] = -Zr[0];          // -Z: the A operand of the V update
         }
         if (!ok) {  // identical in every wave: block-uniform exit
             bad = t;
             break;
         }
-        if (w < 2) {
-            double y[16];
+        const d4 zqf = Zq4;   // zq = D^-1 L^-1 qu: what v needs (Ph4), before the back substitution turns it into Quu^-1 qu
+        // block back substitution W = U^-1 Z (U unit upper): rows of block j are final once the blocks right of it have
+        // been applied; A[row c][k-index g] = U(c, 4 j + g) for the rows c above block j
+        wave_fence();
 #pragma unroll
-            for (int i = 0; i < 16; ++i) y[i] = (w == 0) ? S.Qux[i + kLd16 * lane] : S.qu[i];
-            const double* Lw = S.L[w];
+        for (int j = 3; j >= 1; --j) {
+            const double u = S.U[w][c + kLd16 * (4 * j + g)];
+            const double nU = (c < 4 * j) ? -u : 0.0;
+            Zt = __builtin_amdgcn_mfma_f64_16x16x4f64(nU, Zt[j], Zt, 0, 0, 0);
+            Zq4 = __builtin_amdgcn_mfma_f64_16x16x4f64(nU, Zq4[j], Zq4, 0, 0, 0);
+        }
 #pragma unroll
-            for (int i = 1; i < 16; ++i)
+        for (int r = 0; r < 4; ++r) S.Ko[(g + 4 * r) + kLd16 * col] = -Zt[r];               // K = -Quu^-1 Qux  (riccati.py:120)
+        if (w == 1 && c == 0) {
 #pragma unroll
-                for (int k = 0; k < i; ++k) y[i] = fma(-Lw[i * kLd16 + k], y[k], y[i]);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) y[i] *= invd[i];
-#pragma unroll
-            for (int i = 14; i >= 0; --i)
-#pragma unroll
-                for (int k = i + 1; k < 16; ++k) y[i] = fma(-Lw[k * kLd16 + i], y[k], y[i]);
-            if (w == 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) S.K[i + kLd16 * lane] = -y[i];  // riccati.py:120
-            } else if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) S.kff[i] = -0.5 * y[i];         // riccati.py:121
+            for (int r = 0; r < 4; ++r) {
+                S.kff[g + 4 * r] = -0.5 * Zq4[r];                                         // kff = -1/2 Quu^-1 qu (riccati.py:121)
+                S.zq[g + 4 * r] = zqf[r];
             }
         }
         RIC_TICK(4)
         __syncthreads();
         RIC_TICK(5)
 
-        // ================= Ph4: V(:, w) = Qxx(:, w) + K' Qux(w), v = qx + 2 Qux' kff, outputs ================
+        // ================= Ph4: V(:, w) = Qxx(:, w) - Z' Y(:, w), v = qx - Y' zq, outputs (S.K holds -Z, Q[4] holds Y) ====
         if (S.asym != 0) {   // this step's Cxx is not symmetric (block-uniform): nothing of the step is stored
             bad = t;
             break;
@@ -517,9 +585,9 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         {
             double part = 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part = fma(Q[4][r], S.kff[g + 4 * r], part);
+            for (int r = 0; r < 4; ++r) part = fma(Q[4][r], S.zq[g + 4 * r], part);   // (Y' zq)[col]
             part = xor_sum16(part);
-            vown = colok ? fma(2.0, part, S.qx[col]) : 0.0;  // riccati.py:124
+            vown = colok ? S.qx[col] - part : 0.0;  // v = qx + 2 Qux' kff = qx - Qux' Quu^-1 qu   (riccati.py:124)
         }
 #pragma unroll
         for (int I = 0; I < 4; ++I)
@@ -538,7 +606,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             const int idx = tid + 256 * s4;
             const bool okk = idx < (int)nm;
             const int i = okk ? idx % m : 0, j = okk ? idx / m : 0;
-            r64_st(S.K[i + kLd16 * j], rK, okk ? (unsigned)((nm * (size_t)t + idx) * 8) : kR64NoStore);
+            r64_st(S.Ko[i + kLd16 * j], rK, okk ? (unsigned)((nm * (size_t)t + idx) * 8) : kR64NoStore);
         }
         r64_st(S.kff[tid < m ? tid : 0], rkff, tid < m ? (unsigned)(((size_t)m * t + tid) * 8) : kR64NoStore);
         RIC_TICK(6)
