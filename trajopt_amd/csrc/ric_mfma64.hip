@@ -311,18 +311,23 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 #if RIC_DIAG
     unsigned long long tick_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
 #endif
+    // Cxx_t: wave w fetches columns 16 w .. 16 w + 15, lane = row - whole 512-byte rows, every element once - and hands
+    // them to the block through LDS at the end of Ph1; Ph2 takes its tile AND the mirrored elements (the symmetry check)
+    // from there.  The slice of step t - 1 is requested in Ph3 of step t, two phases before it is staged: requested at the
+    // top of Ph1 (behind the 21 loads of F, which retire in order before it) the stage waited ~2k cycles a step for it.
+    double xs[16];
+    auto fetch_X = [&](int t) {
+        const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane(t);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj)
+            xs[jj] = r64_ld(rCxx, (16 * wu + jj) < n ? voRow : kR64NoStore, (tu * (unsigned)nn + (unsigned)(n * (16 * wu + jj))) * 8u);
+    };
+    fetch_X(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         // ================= Ph1: prefetch, w = 2 V'c + v', P = V' F ==========================================
         fetch_F(t >= 1 ? t - 1 : 0);
         const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane(t);
         d4 Q[5];
-        // Cxx_t: wave w fetches columns 16 w .. 16 w + 15, lane = row - whole 512-byte rows, every element once - and
-        // hands them to the block through LDS at the end of this phase; Ph2 takes its tile AND the mirrored elements
-        // (the symmetry check) from there.
-        double xs[16];
-#pragma unroll
-        for (int jj = 0; jj < 16; ++jj)
-            xs[jj] = r64_ld(rCxx, (16 * wu + jj) < n ? voRow : kR64NoStore, (tu * (unsigned)nn + (unsigned)(n * (16 * wu + jj))) * 8u);
 #pragma unroll
         for (int r = 0; r < 4; ++r)   // Qux tile starts from Cxu'  (riccati.py:110): element (i, col) = Cxu[col][i]
             Q[4][r] = r64_ld(rCxu, voXu[r], tu * (unsigned)nm * 8u);
@@ -463,6 +468,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             if (!(dmax_t <= tol)) S.asym = 1;   // read by everybody behind the next barrier
         }
         stage_F();  // the F image of this step is dead: bring in step t - 1
+        fetch_X(t >= 1 ? t - 1 : 0);   // (unconditional: the last one is a harmless re-load)
         // Quu = L D L' with 4 x 4 blocks (L unit lower BLOCK triangular, D block diagonal), no pivoting: a non-positive
         // scalar pivot inside a block flags the problem for the generic kernel.  In the matrix cores' D layout register
         // r of a 16 x 16 tile holds rows 4 r + g - i.e. ROW BLOCK r - and, for a symmetric tile, that register is at
@@ -500,36 +506,42 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
                 }
             }
             wave_fence();
-            // P = L4 D4 L4' (unit lower L4), Pi = L4^-T D4^-1 L4^-1; P(a, b) at a + 4 b, lower triangle used
-            const double d0 = P[0];
-            const double i0 = rcp_nr(d0);
-            const double l10 = P[1] * i0, l20 = P[2] * i0, l30 = P[3] * i0;
-            const double d1 = fma(-l10, P[1], P[5]);
-            const double i1 = rcp_nr(d1);
-            const double w21 = fma(-l20, P[1], P[6]), w31 = fma(-l30, P[1], P[7]);
-            const double l21 = w21 * i1, l31 = w31 * i1;
-            const double d2 = fma(-l21, w21, fma(-l20, P[2], P[10]));
-            const double i2 = rcp_nr(d2);
-            const double w32 = fma(-l31, w21, fma(-l30, P[2], P[11]));
-            const double l32 = w32 * i2;
-            const double d3 = fma(-l32, w32, fma(-l31, w31, fma(-l30, P[3], P[15])));
-            const double i3 = rcp_nr(d3);
-            ok = ok && (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
-            // N = L4^-1 (unit lower): rows 1..3
-            const double n10 = -l10, n21 = -l21, n32 = -l32;
-            const double n20 = fma(-l21, n10, -l20), n31 = fma(-l32, n21, -l31);
-            const double n30 = fma(-l32, n20, fma(-l31, n10, -l30));
-            // Pi(a, b) = sum_j N(j, a) i_j N(j, b), j >= max(a, b)
-            const double t1 = n10 * i1, t20 = n20 * i2, t21 = n21 * i2, t30 = n30 * i3, t31 = n31 * i3, t32 = n32 * i3;
-            const double p33 = i3, p32 = t32, p31 = t31, p30 = t30;
-            const double p22 = fma(t32, n32, i2), p21 = fma(t32, n31, t21), p20 = fma(t32, n30, t20);
-            const double p11 = fma(t31, n31, fma(t21, n21, i1)), p10 = fma(t31, n30, fma(t21, n20, t1));
-            const double p00 = fma(t30, n30, fma(t20, n20, fma(t1, n10, i0)));
+            // Pi = P^-1 by 2 x 2 blocks, P = [A B'; B C] (lower triangle of P used, P(a, b) at a + 4 b):
+            //   A^-1 = adj(A) / det A,  S = C - B A^-1 B',  S^-1 = adj(S) / det S,
+            //   Pi = [A^-1 + G' S^-1 G, -G' S^-1; -S^-1 G, S^-1],  G = B A^-1
+            // - half the dependent chain of a 4 x 4 L D L' (two reciprocals in sequence instead of four).  P is positive
+            // definite iff a00, det A, s00 and det S are positive (leading minors of P: a00, det A, det A s00, det A det S).
+            const double a00 = P[0], a10 = P[1], a11 = P[5];
+            const double b00 = P[2], b10 = P[3], b01 = P[6], b11 = P[7];      // B = P(2..3, 0..1): B(i, j) = P[2 + i + 4 j]
+            const double c00 = P[10], c10 = P[11], c11 = P[15];
+            const double detA = fma(a00, a11, -(a10 * a10));
+            const double iA = rcp_nr(detA);
+            const double ia00 = a11 * iA, ia10 = -a10 * iA, ia11 = a00 * iA;    // A^-1 (symmetric)
+            // G = B A^-1 (2 x 2)
+            const double g00 = fma(b00, ia00, b01 * ia10), g01 = fma(b00, ia10, b01 * ia11);
+            const double g10 = fma(b10, ia00, b11 * ia10), g11 = fma(b10, ia10, b11 * ia11);
+            // S = C - G B'
+            const double s00 = c00 - fma(g00, b00, g01 * b01);
+            const double s10 = c10 - fma(g10, b00, g11 * b01);
+            const double s11 = c11 - fma(g10, b10, g11 * b11);
+            const double detS = fma(s00, s11, -(s10 * s10));
+            const double iS = rcp_nr(detS);
+            const double p22 = s11 * iS, p32 = -s10 * iS, p33 = s00 * iS;       // S^-1
+            ok = ok && (a00 > 0.0) && (detA > 0.0) && (s00 > 0.0) && (detS > 0.0);
+            // lower-left block -S^-1 G: rows 2..3, columns 0..1
+            const double p20 = -fma(p22, g00, p32 * g10), p21 = -fma(p22, g01, p32 * g11);
+            const double p30 = -fma(p32, g00, p33 * g10), p31 = -fma(p32, g01, p33 * g11);
+            // upper-left block A^-1 - G' (lower-left)
+            const double p00 = ia00 - fma(g00, p20, g10 * p30);
+            const double p10 = ia10 - fma(g01, p20, g11 * p30);
+            const double p11 = ia11 - fma(g01, p21, g11 * p31);
             // the A operand "Pi zero-padded to 16 x 4": A[row c][k-index g] = Pi(c, g) for c < 4 - per-lane 0 / 1 masks
-            double Aop = mk[0] * p00;
-            Aop = fma(mk[1], p10, Aop); Aop = fma(mk[2], p20, Aop); Aop = fma(mk[3], p30, Aop);
-            Aop = fma(mk[4], p11, Aop); Aop = fma(mk[5], p21, Aop); Aop = fma(mk[6], p31, Aop);
-            Aop = fma(mk[7], p22, Aop); Aop = fma(mk[8], p32, Aop); Aop = fma(mk[9], p33, Aop);
+            double Aop = mk[7] * p22, Aop2 = mk[0] * p00;   // (two chains; the late entries last)
+            Aop = fma(mk[8], p32, Aop); Aop2 = fma(mk[1], p10, Aop2);
+            Aop = fma(mk[9], p33, Aop); Aop2 = fma(mk[4], p11, Aop2);
+            Aop = fma(mk[2], p20, Aop); Aop2 = fma(mk[3], p30, Aop2);
+            Aop = fma(mk[5], p21, Aop); Aop2 = fma(mk[6], p31, Aop2);
+            Aop += Aop2;
             const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
             const d4 Xs = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, Sd[k], zero4, 0, 0, 0);   // rows 0..3: X' = Pi Quu(blk, :)
             const d4 Zr = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, R[k], zero4, 0, 0, 0);    // rows 0..3: Z_k = Pi Y_k
