@@ -342,14 +342,17 @@ def backward_of(r):
 def config_line(r, world, stamp, label):
     """One entry of `configs` for an iteration line."""
     roof = roofline_of(r, stamp)
-    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "waves_per_simd", "hbm_frac")
-    return {"workload": label, "n_gpus": world, "steps": r["K"], "warmup": r["W"], "ms": r["elapsed"] / r["K"] * 1e3,
-            # the problem-iterations actually executed in the timed region (= N K unless a problem gave up)
-            "value": world * r["problem_iters"] * r["T"] / r["elapsed"], "unit": "problem-timesteps/s",
-            "problem_iters": r["problem_iters"], "gave_up": r["gave_up"],
-            "roofline": {k: roof[k] for k in keep if k in roof}, "phase_ms": r["phases"],
-            "backward_pass_frac_of_hbm": backward_of(r)["frac_of_hbm_peak"],
-            "plan": {k: v for k, v in r["plan"].items() if k != "pad_"}}
+    keep = ("bound", "kernel", "achieved", "unit", "frac", "avg_launch_ms")
+    out = {"workload": label, "n_gpus": world, "steps": r["K"], "ms": r["elapsed"] / r["K"] * 1e3,
+           # problem-timesteps/s over the problem-iterations actually executed in the timed region (= N K unless a problem gave up)
+           "value": world * r["problem_iters"] * r["T"] / r["elapsed"],
+           "roofline": {k: roof[k] for k in keep if k in roof},
+           "phase_ms": {k: r["phases"][k] for k in KERNEL_PHASES},
+           "backward_frac_of_hbm": backward_of(r)["frac_of_hbm_peak"],
+           "plan": {k: v for k, v in r["plan"].items() if k != "pad_"}}
+    if r["gave_up"]:
+        out["problem_iters"], out["gave_up"] = r["problem_iters"], r["gave_up"]
+    return out
 
 
 def timed_calls(torch, call, reps):
@@ -382,8 +385,7 @@ def backward_dense_line(cx, n, m, T, N, layout, reps=5):
         assert int((out["diverge"] >= 0).sum()) == 0 and bool(torch.isfinite(out["K"]).all())
         b = ab["backward_full" if full else "backward"]
         g = N * T * b / ms / 1e6
-        res[key] = {"ms": ms, "alg_bytes_per_problem_step": b, "value": N * T / ms * 1e3,
-                    "roofline": {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS}}
+        res[key] = {"ms": ms, "bytes_per_problem_step": b, "GBps": g, "frac": g / HBM_PEAK_GBS}
         del out
     del d, lam
     cx.release()
@@ -411,9 +413,9 @@ def riccati_line(cx, n=64, m=16, T=1000, N=1024, reps=3):
     del d, o, keep
     cx.release()
     return {"workload": "C5: TV-LQR Riccati sweep dx=%d du=%d T=%d x %d problems, inputs and outputs resident in HBM" % (n, m, T, N),
-            "ms": ms, "value": N * T / ms * 1e3, "unit": "problem-timesteps/s",
+            "ms": ms, "value": N * T / ms * 1e3,
             "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
-                         "flops_per_problem_step": fl, "hbm_GBps": g, "hbm_frac": g / HBM_PEAK_GBS, "alg_bytes_per_problem_step": b}}
+                         "flops_per_problem_step": fl, "hbm_GBps": g, "hbm_frac": g / HBM_PEAK_GBS, "bytes_per_problem_step": b}}
 
 
 def main():
@@ -495,12 +497,13 @@ def main():
             # executed problem-iterations count; (b) nothing ever gives up (the headline's rule): each of them then
             # takes ~54 growing-lambda sweeps per iteration until lambda overflows, and the launch waits for them.
             q = iteration_line(cx, "quadrotor", 4096, 500, ALL_ALPHAS[:8], 8, 3, 3001, max_lmbda=1e6)
-            configs["c4_quadrotor"] = config_line(q, 1, stamp, "C4: 4096 quadrotors (dx=12 du=4 T=500), 8-alpha line search, max_lmbda=1e6 (reference default): hopeless problems give up, only executed problem-iterations counted")
+            configs["c4_quadrotor"] = config_line(q, 1, stamp, "C4: 4096 quadrotors (dx=12 du=4 T=500), 8 alphas, max_lmbda=1e6 (reference default): hopeless problems give up, only executed problem-iterations counted")
             q = iteration_line(cx, "quadrotor", 4096, 500, ALL_ALPHAS[:8], 8, 3, 3001)
-            configs["c4_quadrotor_never_give_up"] = config_line(q, 1, stamp, "C4 as above with max_lmbda=inf: every problem iterates in every step")
+            configs["c4_quadrotor_never_give_up"] = config_line(q, 1, stamp, "C4 with max_lmbda=inf: every problem iterates in every step")
             configs["c5_riccati"] = riccati_line(cx)
             configs["backward_dense"] = {
-                "note": "backward pass alone, dense synthetic inputs in HBM, lambda=1 reg=1; achieved = SURVEY 8(d) algorithmic bytes / time",
+                "note": "backward pass alone, dense synthetic inputs in HBM, lambda=1 reg=1; roofline per entry: bound hbm, GBps = SURVEY 8(d) "
+                        "algorithmic bytes / time, frac = GBps / 8000",
                 "c2_4096": backward_dense_line(cx, 4, 1, 500, 4096, 1),
                 "c3_8192": backward_dense_line(cx, 6, 1, 500, 8192, 1),
                 "c4_4096": backward_dense_line(cx, 12, 4, 500, 4096, 0),
@@ -531,8 +534,7 @@ def main():
                        "instances_per_gpu": N, "horizon": T, "parallelism": "problems sharded x%d, no collective" % world},
             "roofline": rounded(roofline_of(r, stamp, pmc, sq)),
             "phase_ms": rounded(r["phases"]),
-            "phase_ms_note": "six-phase breakdown: %d iterations bracketed after the timed region; the timed region "
-                             "carries only the dominant kernel's two events per iteration" % r["KB"],
+            "phase_ms_note": "%d iterations bracketed after the timed region (which carries only the dominant kernel's events)" % r["KB"],
             "plan": r["plan"],
             "backward_pass": rounded(backward_of(r)),
             "source_stamp": stamp,

@@ -39,10 +39,15 @@ def main():
         res[k] = d
     by_phase = {}
     for k, d in res.items():
-        for ph, tag in (("rollout", "rollout_kernel"), ("quadratize", "quadratize_kernel"), ("backward", "bwd_"),
-                        ("backward", "fused_qb4_kernel")):
-            if tag in k and d.get("launches", 0) >= by_phase.get(ph, {}).get("launches", 0):
-                by_phase[ph] = d
+        # (the kernel that does a phase's work: the tiled Riccati sweep, not the generic kernel that only redoes the
+        # problems it flags - on a clean batch that one launches, finds nothing to do and leaves)
+        for ph, tag, rank in (("rollout", "rollout_kernel", 1), ("quadratize", "quadratize_kernel", 1), ("backward", "bwd_", 1),
+                              ("backward", "fused_qb4_kernel", 2), ("backward", "fused_tpp_kernel", 2), ("backward", "ric_mfma64_kernel", 3)):
+            if tag in k:
+                key = (rank, d.get("launches", 0))
+                if key >= by_phase.get(ph, ({}, (0, 0)))[1]:
+                    by_phase[ph] = (d, key)
+    by_phase = {ph: v[0] for ph, v in by_phase.items()}
     json.dump({"stamp": _lib.source_stamp(), "workload": workload,
                "units": "means per launch; SQ_* summed over all SIMDs/XCDs", "kernels": res,
                "kernels_by_phase": by_phase}, open(out, "w"), indent=1)

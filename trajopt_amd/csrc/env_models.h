@@ -398,6 +398,46 @@ __device__ __forceinline__ void env_dynamics(const trajopt_env_t& e, const X (&x
     }
 }
 
+// The clip of a double as exactly two instructions.  fmin(fmax(x, -lim), lim) makes hipcc quiet its operands first (a
+// v_max_f64 x, x per limit - and it prefers recomputing those in the time loop to holding them: ten instructions a
+// cartpole step); the hardware instructions already implement minnum / maxnum on any input (IEEE mode quiets a
+// signalling NaN by itself), so the results are the same bit for bit.  nlim = -lim, prepared by the caller.
+__device__ __forceinline__ double clip_hw(double x, double nlim, double lim) {
+    double r;
+    asm("v_max_f64 %0, %1, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(r) : "v"(x), "v"(nlim), "v"(lim));
+    return r;
+}
+__device__ __forceinline__ double max_hw(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// env_dynamics<MODEL, double, false> with the state clip as clip_hw (the rollout's time loop); nxmax = -e.xmax.
+template <int MODEL>
+__device__ __forceinline__ void env_dynamics_hw(const trajopt_env_t& e, const double (&x)[Model<MODEL>::N],
+                                                const double (&u)[Model<MODEL>::M], double (&xn)[Model<MODEL>::N],
+                                                const double (&nxmax)[Model<MODEL>::N]) {
+    constexpr int N = Model<MODEL>::N;
+    const double dt = ReverseTime<MODEL>::value ? -e.dt : e.dt;
+    double k1[N], k2[N], k3[N], k4[N], y[N];
+    Model<MODEL>::f(e, x, u, k1);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = x[i] + (0.5 * dt) * k1[i];
+    Model<MODEL>::f(e, y, u, k2);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = x[i] + (0.5 * dt) * k2[i];
+    Model<MODEL>::f(e, y, u, k3);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = x[i] + dt * k3[i];
+    Model<MODEL>::f(e, y, u, k4);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double s = x[i] + (dt / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        xn[i] = clip_hw(s, nxmax[i], e.xmax[i]);
+    }
+}
+
 // LQR env: xn = A x + B clip(u) + c, no state clip (lqr_v0.py:50-66).  Run-time dims (<= MAX): loops
 // run to the compile-time maximum with guards so the arrays keep static indices (stay in registers).
 template <class X>

@@ -265,36 +265,40 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         // loaded again) - the generic loop below costs ~65 address / copy instructions per step, a sixth of the step.
         static_assert(MINOR && SYS::kStatic, "FAST is instantiated for the struct-of-arrays layout and static dimensions only");
         struct In { double xr[N], ur[M], kf[M], K[M * N], w; };
+        // Every load is  buffer_load_dwordx2 v, v_lane, s[descriptor of the array's current slice], s_element offen :
+        // the descriptor's base is the wave-uniform slice pointer (advanced with two scalar adds a step), the element's
+        // offset a loop-invariant SGPR and the lane's offset ONE VGPR per array - as a flat load every element cost a
+        // 64-bit vector add (base + zero-extended lane offset) and a 64-bit VGPR pair to hold that offset.
         const unsigned np8 = (unsigned)(NP * 8), p8 = (unsigned)(p * 8);
-        unsigned ox[N], ou[M], okf[M], oK[M * N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) ox[i] = (unsigned)i * np8 + p8;
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            ou[j] = (unsigned)j * np8 + p8;
-            okf[j] = KMINOR ? (unsigned)(bank * M + j) * np8 + p8 : (unsigned)((((size_t)bank * NP + p) * Em + j) * 8);
-        }
-#pragma unroll
-        for (int k = 0; k < M * N; ++k)
-            oK[k] = KMINOR ? (unsigned)(bank * M * N + k) * np8 + p8 : (unsigned)((((size_t)bank * NP + p) * Enm + k) * 8);
+        const unsigned vkf = KMINOR ? (unsigned)(bank * M) * np8 + p8 : (unsigned)((((size_t)bank * NP + p) * Em) * 8);
+        const unsigned vK = KMINOR ? (unsigned)(bank * M * N) * np8 + p8 : (unsigned)((((size_t)bank * NP + p) * Enm) * 8);
         const size_t sx = (size_t)N * np8, su = (size_t)M * np8, skf = KMINOR ? kmul * su : (size_t)M * 8,
                      sK = KMINOR ? (size_t)kmul * N * M * np8 : (size_t)N * M * 8;
         const char *pxr = reinterpret_cast<const char*>(a.xref), *pur = reinterpret_cast<const char*>(a.uref),
                    *pK = reinterpret_cast<const char*>(a.K), *pkf = reinterpret_cast<const char*>(a.kff),
                    *pw = reinterpret_cast<const char*>(a.weighting);
-        auto ld = [](const char* b, unsigned o) { return *reinterpret_cast<const double*>(b + o); };
-        // PROBLEM_MAJOR gains: the elements of a step are consecutive - ONE lane offset and the element in the
-        // instruction's immediate, instead of a register per element (48 for the quadrotor's K)
-        auto ldi = [](const char* b, unsigned o, unsigned imm) { return *reinterpret_cast<const double*>(b + (size_t)o + imm); };
+        auto rs = [](const char* b) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b), 0, 0xffffffff, 0x00020000); };
+        auto bl = [](__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) {
+            return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, v, so, 0));
+        };
+        double numax[M], nxmax[N], xtop = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < M; ++j) numax[j] = -e.umax[j];
+#pragma unroll
+        for (int i = 0; i < N; ++i) nxmax[i] = -e.xmax[i];
         int tl = 0;  // the slice the pointers address
         auto load = [&](In& s) {
+            const __amdgpu_buffer_rsrc_t rx = rs(pxr), ru = rs(pur), rk = rs(pK), rf = rs(pkf);
 #pragma unroll
-            for (int i = 0; i < N; ++i) s.xr[i] = ld(pxr, ox[i]);
+            for (int i = 0; i < N; ++i) s.xr[i] = bl(rx, p8, (unsigned)i * np8);
 #pragma unroll
-            for (int j = 0; j < M; ++j) { s.ur[j] = ld(pur, ou[j]); s.kf[j] = KMINOR ? ld(pkf, okf[j]) : ldi(pkf, okf[0], 8u * j); }
+            for (int j = 0; j < M; ++j) {
+                s.ur[j] = bl(ru, p8, (unsigned)j * np8);
+                s.kf[j] = KMINOR ? bl(rf, vkf, (unsigned)j * np8) : bl(rf, vkf + 8u * j, 0u);
+            }
 #pragma unroll
-            for (int k = 0; k < M * N; ++k) s.K[k] = KMINOR ? ld(pK, oK[k]) : ldi(pK, oK[0], 8u * k);
-            s.w = ld(pw, 0u);
+            for (int k = 0; k < M * N; ++k) s.K[k] = KMINOR ? bl(rk, vK, (unsigned)k * np8) : bl(rk, vK + 8u * k, 0u);
+            s.w = *reinterpret_cast<const double*>(pw);
             if (tl + 1 < T) { pxr += sx; pur += su; pK += sK; pkf += skf; pw += 8; ++tl; }
         };
         double* sp[N];
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 double kx = 0.0;
 #pragma unroll
                 for (int i = 0; i < N; ++i) kx = fma(s.K[j + M * i], x[i] - s.xr[i], kx);
-                u[j] = clip_g(fma(alpha, s.kf[j], s.ur[j]) + kx, e.umax[j]);
+                u[j] = clip_hw(fma(alpha, s.kf[j], s.ur[j]) + kx, numax[j], e.umax[j]);
             }
             total += env_cost_plain<N, M>(e, x, u, s.w);  // ilqr.py:98 passes u_last = u_t
             if constexpr (kAhead2 || kOne) load(s);
@@ -338,11 +342,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 else if constexpr (!CO) { *ap[j] = u[j]; ap[j] += dsu; }
             }
             double xn[N];
-            SYS::dynamics_clipped(e, x, u, xn);
+            SYS::dynamics_clipped_hw(e, x, u, xn, nxmax);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 x[i] = xn[i];
-                fin = fin && (x[i] < 1e8);
+                xtop = max_hw(xtop, x[i]);   // all(state < 1e8), ilqr.py:141: a clipped state is never NaN, so the largest one decides
                 if constexpr (TB) { if constexpr (put_next) put_x(t + 1, i, x[i]); }
                 else if constexpr (!CO) { sp[i] += dsx; *sp[i] = x[i]; }
             }
@@ -414,6 +418,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
 #pragma unroll
         for (int j = 0; j < M; ++j) zero[j] = 0.0;
         total += env_cost_plain<N, M>(e, x, zero, a.weighting[T]);  // ilqr.py:101
+        fin = fin && (xtop < 1e8);
         if (live) {
             if (a.ret) a.ret[(size_t)ai * NP + p] = total;
             if (a.finite) a.finite[(size_t)ai * NP + p] = fin ? 1 : 0;
