@@ -65,6 +65,9 @@ static int ric_flags(int32_t** out) {
     return TRAJOPT_OK;
 }
 
+#ifndef RIC_SPREAD
+#define RIC_SPREAD 1   // 1: the phase's global loads are issued between its first matrix-core instructions (below)
+#endif
 #ifndef RIC_DIAG
 #define RIC_DIAG 0   // timing experiments only: 1 = per-phase clock ticks of wave 0 written over v[p][0..7][0] (wrong results)
 #endif
@@ -204,6 +207,12 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         for (int s = 0; s < 4; ++s) fB[s] = r64_ld(rB, vo_tid, (tu * (unsigned)nm + 256u * s) * 8u);
         fc = r64_ld(rc_, vo_c, tu * (unsigned)n * 8u);
     };
+    // one piece of the same prefetch: loads i of 30 (fetch_F = pieces 0 .. 20)
+    auto fetch_F_piece = [&](unsigned tu, int i) {
+        if (i < 16) fA[i] = r64_ld(rA, vo_tid, (tu * (unsigned)nn + 256u * i) * 8u);
+        else if (i < 20) fB[i - 16] = r64_ld(rB, vo_tid, (tu * (unsigned)nm + 256u * (i - 16)) * 8u);
+        else if (i == 20) fc = r64_ld(rc_, vo_c, tu * (unsigned)n * 8u);
+    };
     auto stage_F = [&]() {       // registers -> LDS
 #pragma unroll
         for (int s = 0; s < 16; ++s) S.F[offA[s]] = fA[s];
@@ -325,17 +334,28 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
     fetch_X(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         // ================= Ph1: prefetch, w = 2 V'c + v', P = V' F ==========================================
-        fetch_F(t >= 1 ? t - 1 : 0);
+        // This phase's 30 global loads (F_{t-1}: 21; the Qux tile's start Cxu', riccati.py:110: element (i, col) =
+        // Cxu[col][i]; this wave's part of Quu - wave 0 starts from Cuu, the others read beyond the range: 0.0; the cx /
+        // cu element for the q vectors - threads 0..159, two per column; waves 0, 1: cx, wave 2: cu) are not needed before
+        // Ph2 / Ph3.  The wave issues in order: what stands between two matrix-core instructions runs while the first one
+        // occupies the pipe (64 cycles), what stands in front of the whole run of them does not - so the loads and their
+        // scalar address arithmetic are issued one at a time between the first 32 MFMAs (piece() below) instead of as a
+        // 230-instruction prologue.
         const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane(t);
+        const unsigned tp = (unsigned)__builtin_amdgcn_readfirstlane(t >= 1 ? t - 1 : 0);
         d4 Q[5];
+        d4 qp;
+        double cq;
+        auto piece = [&](int i) {
+            if (i < 21) fetch_F_piece(tp, i);
+            else if (i < 25) Q[4][i - 21] = r64_ld(rCxu, voXu[i - 21], tu * (unsigned)nm * 8u);
+            else if (i < 29) qp[i - 25] = r64_ld(rCuu, voUu[i - 25], tu * (unsigned)mm * 8u);
+            else if (i == 29) cq = r64_ld(rcq, vocq, tu * (unsigned)(wu < 2 ? n : m) * 8u);
+        };
+        if (!RIC_SPREAD) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)   // Qux tile starts from Cxu'  (riccati.py:110): element (i, col) = Cxu[col][i]
-            Q[4][r] = r64_ld(rCxu, voXu[r], tu * (unsigned)nm * 8u);
-        d4 qp;  // this wave's part of Quu; wave 0 starts from Cuu (the others read beyond the range: 0.0)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) qp[r] = r64_ld(rCuu, voUu[r], tu * (unsigned)mm * 8u);
-        // cx / cu element for the q vectors (threads 0..159, two per column; waves 0, 1: cx, wave 2: cu)
-        const double cq = r64_ld(rcq, vocq, tu * (unsigned)(wu < 2 ? n : m) * 8u);
+            for (int i = 0; i < 30; ++i) piece(i);
+        }
         double fb0[16], fb1[16];   // operand tiles, one ahead of the MFMAs
         ld16(fb0, S.F, 80, g);      // the c_t column (every lane the same column)
         ld16(fb1, S.F, c, g);
@@ -363,7 +383,9 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb1[e], a0, 0, 0, 0);
+                if (RIC_SPREAD) { piece(2 * e); __builtin_amdgcn_sched_barrier(0); }
                 a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb0[e], a1, 0, 0, 0);
+                if (RIC_SPREAD) { if (2 * e + 1 < 30) piece(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
             }
             put_P(a0, 0);
             put_P(a1, 1);
