@@ -1,6 +1,7 @@
 // extern "C" entry points of libtrajopt_amd.so (declared in include/trajopt_amd.h) for the backward
 // passes, plus the small utilities.  No CPU fallback exists anywhere: without a HIP device every
 // compute entry point returns TRAJOPT_ERR_NO_DEVICE / TRAJOPT_ERR_HIP.
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -48,7 +49,10 @@ constexpr int64_t kMfma4MaxProblems = 6144;
 // Up to this batch size the column-per-lane kernel (bwd_col8.hip: eight lanes per problem, a step is a third of the
 // dependent instructions but every wave recomputes the shared quantities of its 8 problems) beats lane = problem for
 // dx = 6: 8192 problems are 1024 waves instead of 128.  Beyond it the chip is full either way and the redundancy loses.
-constexpr int64_t kCol8MaxProblems = 24576;
+// Measured (MI355X, T = 500; column kernel / lane kernel): structured cost, whole iLQR iteration - 12 288 problems 5.26 /
+// 5.35 ms, 16 384 5.94 / 5.92, 24 576 9.35 / 8.79; dense cost blocks, backward pass alone, gains-only - 8192 1.05 / 1.56 ms,
+// 10 240 1.69 / 1.45, 12 288 1.87 / 1.48, 24 576 3.16 / 2.40 (full outputs: 2.07 / 2.30, 3.52 / 2.08, 3.84 / 2.14, 6.34 / 4.42).
+constexpr int64_t kCol8MaxProblems = 16384, kCol8MaxProblemsDense = 8192;
 
 static bool tpp_offsets_fit(int n, int64_t NP) { return (double)n * n * (double)NP * 8.0 + 512.0 < 4294967296.0; }
 
@@ -61,7 +65,7 @@ namespace trajopt {
 // dx <= 4, du = 1  ->  lane = problem for the struct-of-arrays layout and dx <= 6 (NP == 1: the two layouts are the
 // same memory)  ->  wave = problem on the fp64 matrix cores (dx + du <= 16, du <= 4; best with PROBLEM_MAJOR, whose
 // per-step slices are contiguous)  ->  workgroup = problem.
-int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want) {
+int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want, bool structured) {
     const bool minor = layout == TRAJOPT_LAYOUT_PROBLEM_MINOR || NP == 1;
     const bool mfma4_ok = minor && m == 1 && n >= 2 && n <= 4 && (double)(T + 2) * n * n * (double)NP * 8.0 < 4294967296.0;
     const bool lane_ok = minor && tpp_offsets_fit(n, NP) &&
@@ -72,7 +76,7 @@ int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want
     switch (want) {
         case TRAJOPT_KERNEL_AUTO:
             if (mfma4_ok && NP <= kMfma4MaxProblems) return TRAJOPT_KERNEL_MFMA4;
-            if (col8_ok && NP <= kCol8MaxProblems) return TRAJOPT_KERNEL_COLUMNS;
+            if (col8_ok && NP <= (structured ? kCol8MaxProblems : kCol8MaxProblemsDense)) return TRAJOPT_KERNEL_COLUMNS;
             if (lane_ok) return TRAJOPT_KERNEL_LANE;
             if (mfma16_ok) return TRAJOPT_KERNEL_MFMA16;
             return wg_ok ? TRAJOPT_KERNEL_WORKGROUP : -1;
@@ -119,7 +123,7 @@ int trajopt_backward_supports_structured_cost(int n, int m, int T, int64_t NP, i
     // du <= 4, either layout); the workgroup kernel does not
     if (n <= 0 || m <= 0 || T <= 0 || NP <= 0) return 0;
     if (layout != TRAJOPT_LAYOUT_PROBLEM_MAJOR && layout != TRAJOPT_LAYOUT_PROBLEM_MINOR) return 0;
-    const int fam = backward_kernel_family(n, m, T, NP, layout, TRAJOPT_KERNEL_AUTO);
+    const int fam = backward_kernel_family(n, m, T, NP, layout, TRAJOPT_KERNEL_AUTO, true);
     return (fam == TRAJOPT_KERNEL_LANE || fam == TRAJOPT_KERNEL_MFMA4 || fam == TRAJOPT_KERNEL_COLUMNS || fam == TRAJOPT_KERNEL_MFMA16) ? 1 : 0;
 }
 
@@ -135,7 +139,7 @@ int trajopt_ilqr_backward_pass_batched(const trajopt_backward_io_t* io, int reg,
     if (retry && !sched) return TRAJOPT_ERR_BAD_ARG;
     trajopt_lambda_schedule_t s = sched ? *sched : trajopt_lambda_schedule_t{1e-6, 1e6, 1.6};
     hipStream_t st = as_stream(stream);
-    const int fam = backward_kernel_family(n, m, T, NP, layout, io->kernel);
+    const int fam = backward_kernel_family(n, m, T, NP, layout, io->kernel, io->cost_w != nullptr);
     if (fam < 0 || (io->cost_w && fam != TRAJOPT_KERNEL_LANE && fam != TRAJOPT_KERNEL_MFMA4 && fam != TRAJOPT_KERNEL_COLUMNS && fam != TRAJOPT_KERNEL_MFMA16)) return TRAJOPT_ERR_UNSUPPORTED;
     bool handled = false;
     int rc = TRAJOPT_OK;

@@ -9,6 +9,7 @@
 // named input register sets: the loads of step t-1 are issued before the arithmetic of step t, so
 // HBM latency hides under the ~250 dependent fp64 FMAs of a step.
 #include <cstdlib>
+#include <type_traits>
 #include "smallmat.h"
 #include "sys.h"
 
@@ -16,7 +17,12 @@ namespace trajopt {
 
 template <int N, int M>
 struct StepIn {
-    double A[N * N], B[N * M], Cxx[N * N], Cuu[M * M], Cxu[N * M], cx[N], cu[M], ur[M];
+    double A[N * N], B[N * M], cx[N], cu[M], ur[M];
+};
+// the cost blocks of a step: read once, as the starting values of Qxx / Quu / Qxu, and dead from there on
+template <int N, int M>
+struct CostIn {
+    double Cxx[N * N], Cuu[M * M], Cxu[N * M];
 };
 
 struct TppArgs {
@@ -47,6 +53,9 @@ struct Lane {
 // sizes this kernel is chosen for nothing of it fits a cache; measured on 65 536 problems, dense inputs (scripts/debug/
 // tpp_nt_sweep.sh): cartpole gains-only 4.81 -> 4.99 TB/s, full 4.74 -> 4.78; double cartpole 3.89 -> 4.08 / 4.35 -> 4.58
 // (nt on the loads alone or the stores alone gives about half of that each).
+#ifndef TPP_PIN
+#define TPP_PIN 1
+#endif
 #ifndef TPP_LD_AUX
 #define TPP_LD_AUX 2
 #endif
@@ -73,11 +82,10 @@ __device__ __forceinline__ void store_vec(double* ubase, const Lane& ln, const d
 
 // SC: structured cost (trajopt_backward_io_t::cost_w): Cxx = w[t] diag(gxx), Cuu = diag(guu), Cxu = 0 are formed in
 // registers (the zeros fold away at compile time) instead of being loaded - 21 of a cartpole step's 51 loads.
-template <int N, int M, bool GN, bool SC>
-__device__ __forceinline__ void load_step(StepIn<N, M>& s, const TppArgs& a, size_t p0, const Lane& off, int t) {
+template <int N, int M, bool SC>
+__device__ __forceinline__ void load_cost(CostIn<N, M>& s, const TppArgs& a, size_t p0, const Lane& off, int t) {
     const size_t NP = a.NP;
-    load_vec<N * N>(s.A, UBASE(a.io.A, N * N, t), off);
-    load_vec<N * M>(s.B, UBASE(a.io.B, N * M, t), off);
+    (void)NP;
     if constexpr (SC) {
         const double w = a.io.cost_w[t];  // wave-uniform: one scalar load, issued a step ahead like the rest
 #pragma unroll
@@ -95,6 +103,12 @@ __device__ __forceinline__ void load_step(StepIn<N, M>& s, const TppArgs& a, siz
         load_vec<M * M>(s.Cuu, UBASE(a.io.Cuu, M * M, t), off);
         load_vec<N * M>(s.Cxu, UBASE(a.io.Cxu, N * M, t), off);
     }
+}
+template <int N, int M, bool GN>
+__device__ __forceinline__ void load_step(StepIn<N, M>& s, const TppArgs& a, size_t p0, const Lane& off, int t) {
+    const size_t NP = a.NP;
+    load_vec<N * N>(s.A, UBASE(a.io.A, N * N, t), off);
+    load_vec<N * M>(s.B, UBASE(a.io.B, N * M, t), off);
     load_vec<N>(s.cx, UBASE(a.io.cx, N, t), off);
     load_vec<M>(s.cu, UBASE(a.io.cu, M, t), off);
     if constexpr (GN) load_vec<M>(s.ur, UBASE(a.io.uref, M, t), off);
@@ -102,24 +116,40 @@ __device__ __forceinline__ void load_step(StepIn<N, M>& s, const TppArgs& a, siz
 
 // One step of util.cpp:128-161.  Returns false when Quu_reg fails the PD test (util.cpp:145-148);
 // in that case Qxx..qu of this step have been stored (as the reference does) and V, v are untouched.
-template <int N, int M, bool FULL, bool GN>
-__device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N * N], double (&v)[N], double lam,
+// inputs_dead() is called once the Q-function blocks stand in registers of their own: nothing of `in` / `cs` is read
+// from there on, and a caller that keeps ONE set of input registers (below: dx = 6, dense cost) re-loads it for the
+// next step at that point.
+struct NoReload { __device__ __forceinline__ void operator()() const {} };
+template <int N, int M, bool FULL, bool GN, class Dead = NoReload>
+__device__ __forceinline__ bool bwd_step(StepIn<N, M>& in, CostIn<N, M>& cs, Dead&& inputs_dead, double (&V)[N * N], double (&v)[N], double lam,
                                          int reg, double& dV0, double& dV1, double (&gmax)[M], const TppArgs& a,
                                          size_t p0, const Lane& off, const Lane& offK, const Lane& offkff, int kmul,
                                          int t) {
     const size_t NP = a.NP;
     (void)NP;
-    // W = V A, Z = V B
-    double W[N * N], Z[N * M];
+    // W = V A, Qxx = Cxx + A^T W  (util.cpp:128) - a column of W at a time: all of W at once is N * N more live
+    // registers at the point where both input sets, V and the cost blocks are live as well (dx = 6 then spilled)
+    double Qxx[N * N];
 #pragma unroll
-    for (int j = 0; j < N; ++j)
+    for (int j = 0; j < N; ++j) {
+        double Wj[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < N; ++k) s = fma(V[i + N * k], in.A[k + N * j], s);
-            W[i + N * j] = s;
+            Wj[i] = s;
         }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double s = cs.Cxx[i + N * j];
+#pragma unroll
+            for (int k = 0; k < N; ++k) s = fma(in.A[k + N * i], Wj[k], s);
+            Qxx[i + N * j] = s;
+        }
+    }
+    // Z = V B
+    double Z[N * M];
 #pragma unroll
     for (int j = 0; j < M; ++j)
 #pragma unroll
@@ -129,24 +159,13 @@ __device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N *
             for (int k = 0; k < N; ++k) s = fma(V[i + N * k], in.B[k + N * j], s);
             Z[i + N * j] = s;
         }
-    // Qxx = Cxx + A^T W            (util.cpp:128)
-    double Qxx[N * N];
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            double s = in.Cxx[i + N * j];
-#pragma unroll
-            for (int k = 0; k < N; ++k) s = fma(in.A[k + N * i], W[k + N * j], s);
-            Qxx[i + N * j] = s;
-        }
     // Qxu = Cxu + A^T Z (N x M) ; Qux = Qxu^T   (util.cpp:130)
     double Qxu[N * M];
 #pragma unroll
     for (int j = 0; j < M; ++j)
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            double s = in.Cxu[i + N * j];
+            double s = cs.Cxu[i + N * j];
 #pragma unroll
             for (int k = 0; k < N; ++k) s = fma(in.A[k + N * i], Z[k + N * j], s);
             Qxu[i + N * j] = s;
@@ -157,7 +176,7 @@ __device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N *
     for (int j = 0; j < M; ++j)
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            double s = in.Cuu[i + M * j];
+            double s = cs.Cuu[i + M * j];
 #pragma unroll
             for (int k = 0; k < N; ++k) s = fma(in.B[k + N * i], Z[k + N * j], s);
             Quu[i + M * j] = s;
@@ -222,6 +241,13 @@ __device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N *
 #pragma unroll
         for (int i = 0; i < M; ++i) Quu_r[i + M * i] += lam;
     }
+    double ur[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) ur[j] = GN ? in.ur[j] : 0.0;
+    constexpr bool kPin = TPP_PIN && !std::is_same<typename std::decay<Dead>::type, NoReload>::value;
+    if constexpr (kPin) __builtin_amdgcn_sched_barrier(0);   // (the re-load neither above the last use of the old values nor below the gains)
+    inputs_dead();
+    if constexpr (kPin) __builtin_amdgcn_sched_barrier(0);
     // PD test + gains (util.cpp:145-152)
     double K[M * N], kff[M];  // K(j, i): M x N column-major
     if constexpr (M == 1) {
@@ -291,6 +317,7 @@ __device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N *
         v[i] = s;
     }
     // V = Qxx + K^T Quu K + K^T Qux + Qux^T K, then symmetrise   (util.cpp:159-161)
+    double W[N * N];
 #pragma unroll
     for (int j = 0; j < N; ++j)
 #pragma unroll
@@ -301,7 +328,7 @@ __device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N *
                 s = fma(K[k + M * i], QK[k + M * j] + Qxu[j + N * k], s);
                 s = fma(Qxu[i + N * k], K[k + M * j], s);
             }
-            W[i + N * j] = s;  // reuse W as the unsymmetrised V
+            W[i + N * j] = s;  // the unsymmetrised V
         }
 #pragma unroll
     for (int j = 0; j < N; ++j)
@@ -318,7 +345,7 @@ __device__ __forceinline__ bool bwd_step(const StepIn<N, M>& in, double (&V)[N *
     }
     if constexpr (GN) {
 #pragma unroll
-        for (int j = 0; j < M; ++j) gmax[j] = nanmax(gmax[j], fabs(kff[j]) / (fabs(in.ur[j]) + 1.0));
+        for (int j = 0; j < M; ++j) gmax[j] = nanmax(gmax[j], fabs(kff[j]) / (fabs(ur[j]) + 1.0));
     }
     return true;
 }
@@ -345,6 +372,7 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
     int div = -1, retries = 0;
     double dV0 = 0.0, dV1 = 0.0;
     double gmax[M];
+    constexpr bool kOneSet = DEPTH == 0;
 
     for (;;) {
         div = -1;
@@ -375,38 +403,81 @@ __global__ __launch_bounds__(64) void bwd_tpp_kernel(TppArgs a) {
         // vmcnt there, which waits for the prefetch just issued and exposes the whole HBM latency every step.
         StepIn<N, M> s0, s1;
         int t = T - 1;
-        load_step<N, M, GN, SC>(s0, a, p0, off, t);
-        if constexpr (DEPTH == 2) {
+        auto clamp = [](int x) { return x >= 0 ? x : 0; };
+#define TPP_STEP(SET, COST, AFTER) bwd_step<N, M, FULL, GN>(SET, COST, AFTER, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)
+        load_step<N, M, GN>(s0, a, p0, off, t);
+        if constexpr (kOneSet) {
+            // Dense cost at dx = 6: two input sets are 2 x 92 doubles, which with V, Qxx ... does not fit 512 registers -
+            // hipcc then parked ~20 doubles of the prefetched set in scratch, each as "load, wait for EVERYTHING in flight,
+            // store": the latency of HBM twenty times a step, plus the traffic (+10 % read, 2 x written).  ONE set instead,
+            // re-loaded for step t - 1 as soon as step t has no more use for it: the loads fly during the last third of the
+            // step's arithmetic (gains, v, V) and are waited for at the top of the next one - the launch is bound by the
+            // bytes, not by that wait.
+            CostIn<N, M> c;
+            load_cost<N, M, SC>(c, a, p0, off, t);
+            auto reload = [&]() {
+                load_step<N, M, GN>(s0, a, p0, off, clamp(t - 1));
+                load_cost<N, M, SC>(c, a, p0, off, clamp(t - 1));
+            };
+            // V leaves every step exactly symmetric (util.cpp:161) - only the terminal Cxx_T need not be.  The first step
+            // runs on the full matrix, the loop carries the 21 distinct entries: 15 loop-carried doubles (and their
+            // copies at the back edge) less.
+            if (!TPP_STEP(s0, c, reload)) div = t;
+            --t;
+            if (div < 0) {
+                double Vs[N * (N + 1) / 2];
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+#pragma unroll
+                    for (int i = j; i < N; ++i) Vs[i * (i + 1) / 2 + j] = V[i + N * j];
+                for (; t >= 0; --t) {
+                    double Vf[N * N];
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+#pragma unroll
+                        for (int i = 0; i < N; ++i) Vf[i + N * j] = i >= j ? Vs[i * (i + 1) / 2 + j] : Vs[j * (j + 1) / 2 + i];
+                    if (!bwd_step<N, M, FULL, GN>(s0, c, reload, Vf, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) { div = t; break; }
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+#pragma unroll
+                        for (int i = j; i < N; ++i) Vs[i * (i + 1) / 2 + j] = Vf[i + N * j];
+                }
+            }
+        } else if constexpr (DEPTH == 2) {
             StepIn<N, M> s2;
-            auto clamp = [](int x) { return x >= 0 ? x : 0; };
-            load_step<N, M, GN, SC>(s1, a, p0, off, clamp(t - 1));
+            CostIn<N, M> c0, c1, c2;
+            load_cost<N, M, SC>(c0, a, p0, off, t);
+            load_step<N, M, GN>(s1, a, p0, off, clamp(t - 1));
+            load_cost<N, M, SC>(c1, a, p0, off, clamp(t - 1));
             while (t >= 0) {
-                load_step<N, M, GN, SC>(s2, a, p0, off, clamp(t - 2));
-                if (!bwd_step<N, M, FULL, GN>(s0, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) { div = t; break; }
+                load_step<N, M, GN>(s2, a, p0, off, clamp(t - 2));
+                load_cost<N, M, SC>(c2, a, p0, off, clamp(t - 2));
+                if (!TPP_STEP(s0, c0, NoReload{})) { div = t; break; }
                 if (--t < 0) break;
-                load_step<N, M, GN, SC>(s0, a, p0, off, clamp(t - 2));
-                if (!bwd_step<N, M, FULL, GN>(s1, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) { div = t; break; }
+                load_step<N, M, GN>(s0, a, p0, off, clamp(t - 2));
+                load_cost<N, M, SC>(c0, a, p0, off, clamp(t - 2));
+                if (!TPP_STEP(s1, c1, NoReload{})) { div = t; break; }
                 if (--t < 0) break;
-                load_step<N, M, GN, SC>(s1, a, p0, off, clamp(t - 2));
-                if (!bwd_step<N, M, FULL, GN>(s2, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) { div = t; break; }
+                load_step<N, M, GN>(s1, a, p0, off, clamp(t - 2));
+                load_cost<N, M, SC>(c1, a, p0, off, clamp(t - 2));
+                if (!TPP_STEP(s2, c2, NoReload{})) { div = t; break; }
                 --t;
             }
-        } else
-        while (t >= 0) {
-            load_step<N, M, GN, SC>(s1, a, p0, off, t >= 1 ? t - 1 : 0);
-            if (!bwd_step<N, M, FULL, GN>(s0, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) {
-                div = t;
-                break;
+        } else {
+            CostIn<N, M> c0, c1;
+            load_cost<N, M, SC>(c0, a, p0, off, t);
+            while (t >= 0) {
+                load_step<N, M, GN>(s1, a, p0, off, clamp(t - 1));
+                load_cost<N, M, SC>(c1, a, p0, off, clamp(t - 1));
+                if (!TPP_STEP(s0, c0, NoReload{})) { div = t; break; }
+                if (--t < 0) break;
+                load_step<N, M, GN>(s0, a, p0, off, clamp(t - 1));
+                load_cost<N, M, SC>(c0, a, p0, off, clamp(t - 1));
+                if (!TPP_STEP(s1, c1, NoReload{})) { div = t; break; }
+                --t;
             }
-            --t;
-            if (t < 0) break;
-            load_step<N, M, GN, SC>(s0, a, p0, off, t >= 1 ? t - 1 : 0);
-            if (!bwd_step<N, M, FULL, GN>(s1, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) {
-                div = t;
-                break;
-            }
-            --t;
         }
+#undef TPP_STEP
         if (div < 0 || !a.retry) break;
         // ilqr.py:166-169
         dlam = fmax(dlam * a.sched.mult_lmbda, a.sched.mult_lmbda);
@@ -541,6 +612,7 @@ __global__ __launch_bounds__(64) void fused_tpp_kernel(FusedTppArgs fa) {
 #pragma unroll
             for (int i = 0; i < N; ++i) ft_st(x[i], rxo, wt ? (unsigned)((((size_t)N * t + i) * NP + p) * 8) : kFtNoStore);
             StepIn<N, M> in;
+            CostIn<N, M> cin;
             {
                 double J[N][N + M];
                 SYS::template jacobian_cols<N + M>(e, x, u, 0, J);
@@ -561,13 +633,13 @@ __global__ __launch_bounds__(64) void fused_tpp_kernel(FusedTppArgs fa) {
                 }
                 in.cx[i] = g;
 #pragma unroll
-                for (int j = 0; j < N; ++j) in.Cxx[i + N * j] = (i == j) ? w * a.io.cost_gxx[i] : 0.0;
-                in.Cxu[i] = 0.0;
+                for (int j = 0; j < N; ++j) cin.Cxx[i + N * j] = (i == j) ? w * a.io.cost_gxx[i] : 0.0;
+                cin.Cxu[i] = 0.0;
             }
             in.cu[0] = sc * 2.0 * e.uw[0] * (e.slew_rate ? (u[0] - ul) : u[0]);
-            in.Cuu[0] = a.io.cost_guu[0];
+            cin.Cuu[0] = a.io.cost_guu[0];
             in.ur[0] = u[0];
-            if (!bwd_step<N, M, false, GN>(in, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) {
+            if (!bwd_step<N, M, false, GN>(in, cin, NoReload{}, V, v, lam, a.reg, dV0, dV1, gmax, a, p0, off, offK, offkff, kmul, t)) {
                 div = t;
                 break;
             }
@@ -658,31 +730,34 @@ static int launch_nms(const TppArgs& a, hipStream_t st) {
     const bool gn = a.io.uref != nullptr && a.io.g_norm != nullptr;
     const dim3 block(64);
     const dim3 grid((unsigned)((a.NP + a.lpw - 1) / a.lpw));
-    // two steps ahead where three register sets fit (dx <= 4) and a SIMD holds few waves of this launch
-    int depth = (N * N + N * M <= 24 && a.NP >= kDepth2MinProblems && a.NP <= kDepth2MaxProblems) ? 2 : 1;
-    if (const char* e = getenv("TRAJOPT_TPP_DEPTH")) { if (N * N + N * M <= 24) depth = atoi(e) == 2 ? 2 : 1; }
-    if constexpr (N * N + N * M <= 24) {
-        if (depth == 2) {
-            if (full) {
-                if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, true, SC, 2>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, false, SC, 2>), grid, block, 0, st, a);
-            } else {
-                if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, true, SC, 2>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, false, SC, 2>), grid, block, 0, st, a);
-            }
-            TRAJOPT_HIP_CHECK(hipGetLastError());
-            return TRAJOPT_OK;
-        }
+    // two steps ahead where three register sets fit (dx <= 4) and a SIMD holds few waves of this launch; none ahead (one
+    // set, re-loaded inside the step) where not even two sets fit (dx = 6 with a dense cost)
+    constexpr bool kTwoFit = N * N + N * M <= 24, kOneOnly = !SC && 2 * (N * N + N * M) + N * N + M * M + N * M > 100;
+    int depth = kOneOnly ? 0 : (kTwoFit && a.NP >= kDepth2MinProblems && a.NP <= kDepth2MaxProblems) ? 2 : 1;
+    if (const char* e = getenv("TRAJOPT_TPP_DEPTH")) {   // experiments
+        const int want = atoi(e);
+        if ((want == 2 && kTwoFit) || want == 1 || (want == 0 && kOneOnly)) depth = want;
     }
-    if (full) {
-        if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, true, SC, 1>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, false, SC, 1>), grid, block, 0, st, a);
-    } else {
-        if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, true, SC, 1>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, false, SC, 1>), grid, block, 0, st, a);
+#define TPP_GO(D)                                                                                             \
+    {                                                                                                         \
+        if (full) {                                                                                           \
+            if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, true, SC, D>), grid, block, 0, st, a);     \
+            else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, true, false, SC, D>), grid, block, 0, st, a);       \
+        } else {                                                                                              \
+            if (gn) hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, true, SC, D>), grid, block, 0, st, a);    \
+            else hipLaunchKernelGGL((bwd_tpp_kernel<N, M, false, false, SC, D>), grid, block, 0, st, a);      \
+        }                                                                                                     \
+        TRAJOPT_HIP_CHECK(hipGetLastError());                                                                 \
+        return TRAJOPT_OK;                                                                                    \
     }
-    TRAJOPT_HIP_CHECK(hipGetLastError());
-    return TRAJOPT_OK;
+    if constexpr (kTwoFit) {
+        if (depth == 2) TPP_GO(2)
+    }
+    if constexpr (kOneOnly) {
+        if (depth == 0) TPP_GO(0)
+    }
+    TPP_GO(1)
+#undef TPP_GO
 }
 template <int N, int M>
 static int launch_nm(const TppArgs& a, hipStream_t st) {

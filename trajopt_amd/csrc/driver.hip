@@ -31,7 +31,7 @@ int launch_fused_tpp(const trajopt_env_t* env, const trajopt_backward_io_t& io, 
                      hipStream_t st);
 bool rollout_straight_line(int n, int m, size_t NP, int nb_alphas);
 bool rollout_cost_only_supported(const trajopt_env_t* env, int T, int64_t NP, int k_layout);
-int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want);
+int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want, bool structured);
 int launch_fused_qb4(const trajopt_env_t* env, const trajopt_backward_io_t& io, int reg, int T, int64_t NP, int retry,
                      const trajopt_lambda_schedule_t& sched, const double* xref, const double* uref,
                      const RefView* rv, hipStream_t st);
@@ -430,7 +430,7 @@ int trajopt_ilqr_plan(const trajopt_env_t* env, const trajopt_ilqr_options_t* op
     const bool staged = ls == 1;
     plan->staged_line_search = ls;
     plan->backward_kernel = plan->fused_quad_bwd == 1 ? TRAJOPT_KERNEL_MFMA4 : plan->fused_quad_bwd == 2 ? TRAJOPT_KERNEL_LANE
-                                                      : backward_kernel_family(n, m, T, NP, GL, TRAJOPT_KERNEL_AUTO);
+                                                      : backward_kernel_family(n, m, T, NP, GL, TRAJOPT_KERNEL_AUTO, plan->structured_cost != 0);
     // (the fast rollout variant at all: built-in model, plain cost - rollout.hip)
     const bool fast = env->model != TRAJOPT_ENV_LQR && !env->slew_rate && env->periodic == 0 && !env->cost_times_dt && env->nb_features == 0;
     plan->rollout_straight_line = fast && ls == 0 && rollout_straight_line(n, m, (size_t)NP, opt->nb_alphas);
