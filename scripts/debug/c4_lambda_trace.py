@@ -1,6 +1,6 @@
 """How many lambda-retry sweeps does the backward pass of the C4 bench workload take, per problem and iteration?
 Replays each iteration's backward pass (same quadratisation, same lambda / dlambda going in) through the batched entry
-and derives the retries from dlambda (ilqr.py:166-167).  python scripts/debug/c4_lambda_trace.py [N] [iters] [nalphas]"""
+and derives the retries from dlambda (ilqr.py:166-167).  python scripts/debug/c4_lambda_trace.py [N] [iters] [nalphas] [max_lmbda]"""
 import os
 import sys
 sys.path.insert(0, os.getcwd())
@@ -13,6 +13,7 @@ from trajopt_amd.ilqr import BatchedILQR
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 NA = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+MAXL = float(sys.argv[4]) if len(sys.argv) > 4 else float("inf")
 T = 500
 al = np.power(10., np.linspace(0, -3, 11))[:NA]
 pe = envs.make("quadrotor", dt=0.02, uw=1e-3)
@@ -20,9 +21,9 @@ rng = np.random.Generator(np.random.PCG64(3001))
 x0 = np.asarray(pe.x0)[None] + rng.multivariate_normal(np.zeros(12), pe.sigma0, size=N)
 kff0 = 1e-4 * rng.standard_normal((N, 4, T))
 s = BatchedILQR(pe, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False, alphas=al,
-                tolfun=-float("inf"), tolgrad=0.0, max_lmbda=float("inf"), trace_cap=ITERS + 8)
+                tolfun=-float("inf"), tolgrad=0.0, max_lmbda=MAXL, trace_cap=ITERS + 8)
 s.init_rollout()
-sched = LambdaSchedule(1e-6, float("inf"), 1.6)
+sched = LambdaSchedule(1e-6, MAXL, 1.6)
 for it in range(ITERS):
     lam0, dl0 = s.lmbda.clone(), s.dlmbda.clone()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -5,7 +5,9 @@
 // instantiated for the shapes the reference's own examples use and these kernels take the rest - the role bwd_wg.hip
 // plays for the iLQR pass.  One 64-lane workgroup per problem; every matrix of a step lives in LDS (column-major,
 // run-time dimensions), the lanes share the elements of each product, the du x du test / inverse runs on lane 0.
-// Built for coverage, not speed: PROBLEM_MINOR accesses of one problem are strided, nothing is prefetched.
+// Built for coverage, not speed: PROBLEM_MINOR accesses of one problem are strided.  The two backward passes fetch the
+// inputs of step t - 1 into registers while step t computes (gw::Pre) and park them in the LDS images once the step has
+// no more use for those; the wide belief-space operands (T, X, V, Z, U, Y) are streamed from global memory as they are used.
 #include "gps_common.h"
 
 namespace trajopt {
@@ -26,6 +28,31 @@ __device__ __forceinline__ void l2g(double* a, int E, int t, const Acc& x, const
     if (!a) return;
     for (int e = lane; e < E; e += kW) a[((size_t)t * E + e) * x.NP + x.p] = src[e];
 }
+// A lane's share of an E-element array (elements lane, lane + 64, ...) of ONE step, held in registers: fetched a step
+// ahead, parked in the array's LDS image when the step that is computing has no more use for the image.  SLOTS covers the
+// largest array the kernel takes; the slots beyond E cost a scalar compare each.
+template <int SLOTS>
+struct Pre {
+    double r[SLOTS];
+    __device__ __forceinline__ void fetch(const double* a, int E, int t, const Acc& x, int lane) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            r[s] = 0.0;
+            if (kW * s < E) {   // wave-uniform
+                const int e = lane + kW * s;
+                r[s] = gl(a, (size_t)E, t, (size_t)(e < E ? e : 0), x);
+            }
+        }
+    }
+    __device__ __forceinline__ void park(double* dst, int E, int lane) const {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (kW * s < E) {
+                const int e = lane + kW * s;
+                if (e < E) dst[e] = r[s];
+            }
+    }
+};
 // C (r x c) = beta C0 + alpha op(A) op(B), inner dimension k; column-major with leading dimensions lda / ldb of the
 // STORED matrices; C must not alias an operand.
 __device__ __forceinline__ void mm(double* C, int r, int c, int k, const double* A, int lda, bool tA, const double* B,
@@ -129,6 +156,11 @@ struct GpsGenArgs {
     int n, m, T;
 };
 
+// SL: register slots per lane of the one-step-ahead input fetch for the dx x dx arrays (64 SL >= dx^2; dx x du and du x du
+// arrays likewise) - 0: none, every step's inputs go straight into the LDS images.  Sized for dx = 32 (16 slots an array)
+// the fetch registers left one wave per SIMD, and the waves that share a SIMD hide more latency than a lone wave's
+// prefetch: dx = 8, du = 4 took 9.1 instead of 3.4 ms.  The launcher picks per shape what measured ahead.
+template <int SL>
 __global__ __launch_bounds__(64) void gps_generic_kernel(GpsGenArgs a) {
     using namespace gw;
     extern __shared__ __align__(16) double sm[];
@@ -151,12 +183,35 @@ __global__ __launch_bounds__(64) void gps_generic_kernel(GpsGenArgs a) {
     l2g(io.v, n, T, x, v, lane);
     if (lane == 0) io.v0[(size_t)T * x.NP + x.p] = v0;
     int status = 0, where = -1;
+    // inputs: step T - 1 straight into the LDS images, every later step through registers, one step ahead
+    // (dx <= 32, du <= 16: at most 1024 / 512 / 256 elements an array = 16 / 8 / 4 per lane)
+    constexpr int kS = SL > 0 ? SL : 1;
+    Pre<kS> pA, pCx, pSg, pB, pCxu, pCuu;
+    Pre<1> pc, pcx, pcu;
+    g2l(A, io.A, nn, T - 1, x, lane); g2l(B, io.B, nm, T - 1, x, lane); g2l(c, io.c, n, T - 1, x, lane);
+    g2l(Cx, io.Cxx, nn, T - 1, x, lane); g2l(Cuu, io.Cuu, mm2, T - 1, x, lane); g2l(Cxu, io.Cxu, nm, T - 1, x, lane);
+    g2l(cx, io.cx, n, T - 1, x, lane); g2l(cu, io.cu, m, T - 1, x, lane); g2l(Sg, io.sigma_dyn, nn, T - 1, x, lane);
+    double c0n = gl(io.c0, 1, T - 1, 0, x), aln = gl(io.alpha, 1, T - 1, 0, x);
     for (int t = T - 1; t >= 0; --t) {
-        g2l(A, io.A, nn, t, x, lane); g2l(B, io.B, nm, t, x, lane); g2l(c, io.c, n, t, x, lane);
-        g2l(Cx, io.Cxx, nn, t, x, lane); g2l(Cuu, io.Cuu, mm2, t, x, lane); g2l(Cxu, io.Cxu, nm, t, x, lane);
-        g2l(cx, io.cx, n, t, x, lane); g2l(cu, io.cu, m, t, x, lane); g2l(Sg, io.sigma_dyn, nn, t, x, lane);
-        const double c0t = gl(io.c0, 1, t, 0, x), al = gl(io.alpha, 1, t, 0, x), na = -1.0 / al;
+        if constexpr (SL == 0) {
+            if (t < T - 1) {
+                g2l(A, io.A, nn, t, x, lane); g2l(B, io.B, nm, t, x, lane); g2l(c, io.c, n, t, x, lane);
+                g2l(Cx, io.Cxx, nn, t, x, lane); g2l(Cuu, io.Cuu, mm2, t, x, lane); g2l(Cxu, io.Cxu, nm, t, x, lane);
+                g2l(cx, io.cx, n, t, x, lane); g2l(cu, io.cu, m, t, x, lane); g2l(Sg, io.sigma_dyn, nn, t, x, lane);
+                c0n = gl(io.c0, 1, t, 0, x);
+                aln = gl(io.alpha, 1, t, 0, x);
+            }
+        }
+        const double c0t = c0n, al = aln, na = -1.0 / al;
         __syncthreads();
+        if constexpr (SL > 0) {   // unconditional (the last one re-loads step 0)
+            const int tn = t >= 1 ? t - 1 : 0;
+            pA.fetch(io.A, nn, tn, x, lane); pB.fetch(io.B, nm, tn, x, lane); pc.fetch(io.c, n, tn, x, lane);
+            pCx.fetch(io.Cxx, nn, tn, x, lane); pCuu.fetch(io.Cuu, mm2, tn, x, lane); pCxu.fetch(io.Cxu, nm, tn, x, lane);
+            pcx.fetch(io.cx, n, tn, x, lane); pcu.fetch(io.cu, m, tn, x, lane); pSg.fetch(io.sigma_dyn, nn, tn, x, lane);
+            c0n = gl(io.c0, 1, tn, 0, x);
+            aln = gl(io.alpha, 1, tn, 0, x);
+        }
         mm(W, n, n, n, V, n, false, A, n, false, 1.0, nullptr, 0.0, lane);
         mm(Z, n, m, n, V, n, false, B, n, false, 1.0, nullptr, 0.0, lane);
         mm(Vc, n, 1, n, V, n, false, c, n, false, 1.0, nullptr, 0.0, lane);
@@ -176,6 +231,12 @@ __global__ __launch_bounds__(64) void gps_generic_kernel(GpsGenArgs a) {
         for (int i = lane; i < n; i += kW) part = fma(c[i], Vc[i] + v[i], part);
         const double q0 = na * (c0t + v0 + wsum(part));
         __syncthreads();
+        // the input images are dead: step t - 1 moves in (read behind the barrier at the top of the next step)
+        if constexpr (SL > 0) {
+        pA.park(A, nn, lane); pB.park(B, nm, lane); pc.park(c, n, lane);
+        pCx.park(Cx, nn, lane); pCuu.park(Cuu, mm2, lane); pCxu.park(Cxu, nm, lane);
+        pcx.park(cx, n, lane); pcu.park(cu, m, lane); pSg.park(Sg, nn, lane);
+        }
         for (int e = lane; e < nm; e += kW) Qux[(e / n) + m * (e % n)] = Qxu[e];   // (j, i) <- (i, j)
         l2g(io.Qxx, nn, t, x, Qxx, lane); l2g(io.Quu, mm2, t, x, Quu, lane);
         l2g(io.qx, n, t, x, qx, lane); l2g(io.qu, m, t, x, qu, lane);
@@ -234,8 +295,17 @@ int launch_gps_backward_generic(const trajopt_gps_backward_io_t& io, int n, int 
     GpsGenArgs a;
     a.io = io; a.NP = (size_t)NP; a.n = n; a.m = m; a.T = T;
     const size_t lds = sizeof(double) * (size_t)(7 * n * n + 6 * n * m + 5 * m * m + 6 * n + 3 * m + 4);
-    TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)gps_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(gps_generic_kernel, dim3((unsigned)NP), dim3(64), lds, st, a);
+    const int big = n > m ? n : m;
+#define GW_GO(SL)                                                                                                          \
+    {                                                                                                                      \
+        TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)gps_generic_kernel<SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(gps_generic_kernel<SL>, dim3((unsigned)NP), dim3(64), lds, st, a);                              \
+    }
+    // Measured (MI355X, T = 100, 4096 problems; no fetch ahead / with): dx = 8, du = 4 (one slot) 3.39 / 4.07 ms - four waves
+    // a SIMD without it, three with: the fourth wave hides more than the fetch; dx = 12, du = 4 (four slots) 7.46 / 5.58 ms.
+    if (big > 8 && big <= 16) GW_GO(4)      // every array within 256 elements
+    else GW_GO(0)
+#undef GW_GO
     TRAJOPT_HIP_CHECK(hipGetLastError());
     return TRAJOPT_OK;
 }
@@ -577,10 +647,17 @@ __global__ __launch_bounds__(64) void bsp_generic_kernel(BspGenArgs a) {
     l2g(io.tau, bb, T, x, tau, lane);
     double dS0 = 0.0, dS1 = 0.0;
     int where = -1;
+    // the dense inputs one step ahead through registers (b, du <= 8: at most 64 elements an array, one per lane)
+    Pre<1> pF, pG, pR, pP, pQ;
+    g2l(F, io.F, bb, T - 1, x, lane); g2l(G, io.G, bm, T - 1, x, lane); g2l(R, io.R, mm2, T - 1, x, lane);
+    g2l(P, io.P, bm, T - 1, x, lane); g2l(Q, io.Q, bb, T - 1, x, lane);
     for (int t = T - 1; t >= 0; --t) {
-        g2l(F, io.F, bb, t, x, lane); g2l(G, io.G, bm, t, x, lane); g2l(R, io.R, mm2, t, x, lane);
-        g2l(P, io.P, bm, t, x, lane); g2l(Q, io.Q, bb, t, x, lane);
         __syncthreads();
+        {
+            const int tn = t >= 1 ? t - 1 : 0;
+            pF.fetch(io.F, bb, tn, x, lane); pG.fetch(io.G, bm, tn, x, lane); pR.fetch(io.R, mm2, tn, x, lane);
+            pP.fetch(io.P, bm, tn, x, lane); pQ.fetch(io.Q, bb, tn, x, lane);
+        }
         mm(SF, b, b, b, S, b, false, F, b, false, 1.0, nullptr, 0.0, lane);
         mm(SG, b, m, b, S, b, false, G, b, false, 1.0, nullptr, 0.0, lane);
         // the linear terms (:152-158): one output per lane, the wide operands (b^2 rows) streamed from global memory
@@ -625,6 +702,7 @@ __global__ __launch_bounds__(64) void bsp_generic_kernel(BspGenArgs a) {
             for (int k = lane; k < mm2; k += kW) Dr[k] = D[k] + ((k % m == k / m) ? lam : 0.0);
         }
         __syncthreads();
+        pF.park(F, bb, lane); pG.park(G, bm, lane); pR.park(R, mm2, lane); pP.park(P, bm, lane); pQ.park(Q, bb, lane);
         if (lane == 0) {   // :170-175
             const bool pd = sympd_serial(Dr, m, wk);
             double det = 0.0;
