@@ -357,62 +357,100 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             for (int i = 0; i < 30; ++i) piece(i);
         }
         double fb0[16], fb1[16];   // operand tiles, one ahead of the MFMAs
-        ld16(fb0, S.F, 80, g);      // the c_t column (every lane the same column)
+        double fb2[16], fb3[16];
         ld16(fb1, S.F, c, g);
-        {
-            double vc = 0.0;  // (V'c)[col] = sum_k V'[col][k] c[k], k = 16 kt + 4 s + g on this lane
-#pragma unroll
-            for (int e = 0; e < 16; ++e) vc = fma(Vt[e >> 2][e & 3], fb0[e], vc);
-            vc = xor_sum16(vc);
-            if (g == 0) S.w[pk(col)] = fma(2.0, vc, vown);  // riccati.py:112-116
-        }
+        ld16(fb0, S.F, 16 + c, g);
+        ld16(fb2, S.F, 80, g);      // the c_t column (every lane the same column): for w below
         // Two tiles at a time, their MFMAs alternating: a chain of 16 MFMAs on one accumulator leaves the matrix pipe
         // idle between dependent issues, two independent chains keep it busy.
-        d4 Pw4;
-        double fb2[16], fb3[16];
-        ld16(fb0, S.F, 16 + c, g);
+        d4 Pw4, pa, pb;   // (pa, pb: finished tiles on their way to LDS)
         auto put_P = [&](const d4& acc, int J) {   // rows 16 w + g + 4 r of column 16 J + c: positions 16 g + 4 w + r
             r64_d2* dst = reinterpret_cast<r64_d2*>(&S.P[(16 * J + c) * kLdk + 16 * g + 4 * w]);
             dst[0] = r64_d2{acc[0], acc[1]};
             dst[1] = r64_d2{acc[2], acc[3]};
         };
         {
-            ld16(fb2, S.F, 32 + c, g);
-            ld16(fb3, S.F, 48 + c, g);
+            // Everything else the phase has to do rides in the shadow of these 32 MFMAs, one piece a slot (RIC_SPREAD): the
+            // global loads, w = 2 V'c + v' (riccati.py:112-116; a chain of 16 FMAs that each wait for an LDS operand - in
+            // front of the MFMAs it cost the phase ~600 cycles a step) and the operand reads of the next two tiles.
+            double vc = 0.0;  // (V'c)[col] = sum_k V'[col][k] c[k], k = 16 kt + 4 s + g on this lane
+            auto side = [&](int slot) {
+                if (slot < 16) vc = fma(Vt[slot >> 2][slot & 3], fb2[slot], vc);
+                else if (slot == 16) vc += __shfl_xor(vc, 16, 64);
+                else if (slot == 18) vc += __shfl_xor(vc, 32, 64);
+                else if (slot == 20) { if (g == 0) S.w[pk(col)] = fma(2.0, vc, vown); }
+                else if (slot == 22) ld16(fb2, S.F, 32 + c, g);
+                else if (slot == 26) ld16(fb3, S.F, 48 + c, g);
+            };
+            if (!RIC_SPREAD) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) side(k);
+            }
             d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb1[e], a0, 0, 0, 0);
-                if (RIC_SPREAD) { piece(2 * e); __builtin_amdgcn_sched_barrier(0); }
+                if (RIC_SPREAD) { piece(2 * e); side(2 * e); __builtin_amdgcn_sched_barrier(0); }
                 a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb0[e], a1, 0, 0, 0);
-                if (RIC_SPREAD) { if (2 * e + 1 < 30) piece(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
+                if (RIC_SPREAD) { if (2 * e + 1 < 30) piece(2 * e + 1); side(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
             }
-            put_P(a0, 0);
-            put_P(a1, 1);
+            pa = a0;
+            pb = a1;
         }
         {
-            ld16(fb1, S.F, 64 + c, g);
+            // tiles 2, 3; in their shadow: the B block column's operands, the first two tiles' way to LDS
             d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb2[e], a0, 0, 0, 0);
+                if (RIC_SPREAD) {
+                    if (e == 0) ld16(fb1, S.F, 64 + c, g);
+                    if (e == 2) put_P(pa, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb3[e], a1, 0, 0, 0);
+                if (RIC_SPREAD) {
+                    if (e == 2) put_P(pb, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            put_P(a0, 2);
-            put_P(a1, 3);
+            if (!RIC_SPREAD) { ld16(fb1, S.F, 64 + c, g); put_P(pa, 0); put_P(pb, 1); }
+            pa = a0;
+            pb = a1;
         }
         {
-            // the B block column: two half-chains, added at the end
+            // the B block column: two half-chains, added at the end; in their shadow: tiles 2, 3 to LDS and this wave's
+            // 16 columns of Cxx_t (requested in Ph3 of the previous step) into the block's image
             d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb1[e], a0, 0, 0, 0);
+                if (RIC_SPREAD) {
+                    if (e == 1) put_P(pa, 2);
+                    if (e >= 2) {
+                        S.X[(16 * w + 2 * (e - 2)) * kLdk + pk(lane)] = xs[2 * (e - 2)];
+                        S.X[(16 * w + 2 * (e - 2) + 1) * kLdk + pk(lane)] = xs[2 * (e - 2) + 1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[(e + 8) >> 2][(e + 8) & 3], fb1[e + 8], a1, 0, 0, 0);
+                if (RIC_SPREAD) {
+                    if (e == 1) put_P(pb, 3);
+                    if (e >= 6) {
+                        S.X[(16 * w + 12 + 2 * (e - 6)) * kLdk + pk(lane)] = xs[12 + 2 * (e - 6)];
+                        S.X[(16 * w + 12 + 2 * (e - 6) + 1) * kLdk + pk(lane)] = xs[12 + 2 * (e - 6) + 1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!RIC_SPREAD) {
+                put_P(pa, 2);
+                put_P(pb, 3);
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) S.X[(16 * w + jj) * kLdk + pk(lane)] = xs[jj];
             }
             Pw4 = a0 + a1;
         }
-#pragma unroll
-        for (int jj = 0; jj < 16; ++jj) S.X[(16 * w + jj) * kLdk + pk(lane)] = xs[jj];
         RIC_TICK(0)
         __syncthreads();
         RIC_TICK(1)
