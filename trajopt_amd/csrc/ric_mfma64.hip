@@ -456,67 +456,111 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         RIC_TICK(1)
 
         // ================= Ph2: Q(:, w) = C(:, w) + F' P(:, w), Quu part, q vectors ===========================
+        // As in Ph1, everything that is not a matrix-core instruction rides in their shadows, a piece a slot: the symmetry
+        // check of this wave's Cxx tiles (each element against its mirror: |C_ij - C_ji| <= 1e-13 max |C|), the operand
+        // reads of the later tiles and [qx; qu] = [cx; cu] + F'w (riccati.py:112-116: two lanes a column, 32 products
+        // each; the lanes beyond the 160 that have a column run along on the last one).  In front of / behind the MFMAs
+        // they cost the phase ~1.2k cycles a step.
         double dmax_t;
         {
-            double cmax_t;
-            double qi[16], mi[16];
+            double qi[16], Pc[16];
             ld16(qi, S.X, col, g);             // elements (16 I + g + 4 r, col)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {     // their mirrors (col, 16 I + g + 4 r)
-                mi[e] = S.X[(16 * (e >> 2) + g + 4 * (e & 3)) * kLdk + pk(col)];
-                Q[e >> 2][e & 3] = qi[e];
-            }
-            sym_lane(Q, mi, dmax_t, cmax_t);
-            if (lane == 0) S.cmax[w] = cmax_t;
-        }
-        {
-            double Pc[16];
             ld16(Pc, S.P, 16 * w + c, g);
-            double fb2[16], fb3[16];
             ld16(fb0, S.F, c, g);
             ld16(fb1, S.F, 16 + c, g);
-            ld16(fb2, S.F, 32 + c, g);
-            ld16(fb3, S.F, 48 + c, g);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Q[e >> 2][e & 3] = qi[e];
+            double dm = 0.0, cm = 0.0, poison = 0.0, mi0 = 0.0, mi1 = 0.0;
+            auto mirror = [&](int e) { return S.X[(16 * (e >> 2) + g + 4 * (e & 3)) * kLdk + pk(col)]; };   // (col, 16 I + g + 4 r)
+            auto sym = [&](int e, double mi) {   // sym_lane(), one element
+                const double d = qi[e] - mi;
+                dm = fmax(dm, fabs(d));
+                cm = fmax(cm, fabs(mi));
+                poison = fma(d, 0.0, poison);
+                // (an IR pass otherwise sinks these to their first use behind the phase, out of the slot they were put in)
+                asm volatile("" : "+v"(dm), "+v"(cm), "+v"(poison));
+            };
+            const int qcol = (tid >> 1) < 80 ? (tid >> 1) : 79, half = tid & 1;
+            const r64_d2* fcol = reinterpret_cast<const r64_d2*>(&S.F[qcol * kLdk + 32 * half]);
+            const r64_d2* wv = reinterpret_cast<const r64_d2*>(&S.w[32 * half]);
+            double s0 = 0.0, s1 = 0.0;
+            r64_d2 gf = {0.0, 0.0}, gw = {0.0, 0.0};
+            double fq[4];   // k = 16 w + 4 s + g of B's column c: position 16 g + 4 w + s
+            auto sideA = [&](int slot) {   // 32 slots under Q[0], Q[1]
+                // mirrors: read in slot e (two at a time in flight), compared two slots later
+                if (slot >= 2 && slot < 18) sym(slot - 2, (slot & 1) ? mi1 : mi0);
+                if (slot < 16) { if (slot & 1) mi1 = mirror(slot); else mi0 = mirror(slot); }
+                if (slot == 18) ld16(fb2, S.F, 32 + c, g);
+                if (slot == 22) ld16(fb3, S.F, 48 + c, g);
+                if (slot >= 26) {   // max |C| over the wave
+                    const int o = 32 >> (slot - 26);
+                    cm = fmax(cm, __shfl_xor(cm, o, 64));
+                }
+            };
+            auto sideB = [&](int slot) {   // 32 slots under Q[2], Q[3]
+                if (slot == 0) { if (lane == 0) S.cmax[w] = cm; }
+                if (slot == 1) ld16(fb0, S.F, 64 + c, g);
+                if (slot == 3) {
+#pragma unroll
+                    for (int sq = 0; sq < 4; ++sq) fq[sq] = S.F[(64 + c) * kLdk + 16 * g + 4 * w + sq];
+                }
+                // the q vectors: pair k of 16 read in slot 6 + k... and multiplied a slot later
+                if (slot >= 7 && slot < 23) { s0 = fma(gf[0], gw[0], s0); s1 = fma(gf[1], gw[1], s1); }
+                if (slot >= 6 && slot < 22) { gf = fcol[slot - 6]; gw = wv[slot - 6]; }
+            };
+            if (!RIC_SPREAD) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) sideA(k);
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {   // two independent accumulator chains at a time (see Ph1)
                 Q[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[e], Pc[e], Q[0], 0, 0, 0);
+                if (RIC_SPREAD) { sideA(2 * e); __builtin_amdgcn_sched_barrier(0); }
                 Q[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[e], Pc[e], Q[1], 0, 0, 0);
+                if (RIC_SPREAD) { sideA(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
             }
-            ld16(fb0, S.F, 64 + c, g);
-            double fq[4];   // k = 16 w + 4 s + g of B's column c: position 16 g + 4 w + s
+            dmax_t = dm + poison;
+            if (!RIC_SPREAD) {
 #pragma unroll
-            for (int sq = 0; sq < 4; ++sq) fq[sq] = S.F[(64 + c) * kLdk + 16 * g + 4 * w + sq];
+                for (int k = 0; k < 32; ++k) sideB(k);
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 Q[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb2[e], Pc[e], Q[2], 0, 0, 0);
+                if (RIC_SPREAD) { sideB(2 * e); __builtin_amdgcn_sched_barrier(0); }
                 Q[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb3[e], Pc[e], Q[3], 0, 0, 0);
+                if (RIC_SPREAD) { sideB(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
             }
+            double sum = s0 + s1;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 Q[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[e], Pc[e], Q[4], 0, 0, 0);
-                if ((e & 3) == 3) qp = __builtin_amdgcn_mfma_f64_16x16x4f64(fq[e >> 2], Pw4[e >> 2], qp, 0, 0, 0);
+                if (RIC_SPREAD) {
+                    if (e == 0) sum += __shfl_xor(sum, 1, 64);
+                    if (e == 2) {
+                        if (tid < 160 && half == 0) {
+                            if (qcol < 64) S.qx[qcol] = cq + sum;
+                            else S.qu[qcol - 64] = cq + sum;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if ((e & 3) == 3) {
+                    qp = __builtin_amdgcn_mfma_f64_16x16x4f64(fq[e >> 2], Pw4[e >> 2], qp, 0, 0, 0);
+                    if (RIC_SPREAD) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!RIC_SPREAD) {
+                sum += __shfl_xor(sum, 1, 64);
+                if (tid < 160 && half == 0) {
+                    if (qcol < 64) S.qx[qcol] = cq + sum;
+                    else S.qu[qcol - 64] = cq + sum;
+                }
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             S.QuuP[w][(g + 4 * r) + kLd16 * c] = qp[r];   // (the Qux tile Q[4] stays in this wave's registers)
-        }
-        if (tid < 160) {  // [qx; qu] = [cx; cu] + F' w   (riccati.py:112-116)
-            const int qc = tid >> 1, half = tid & 1;
-            const double* fcol = &S.F[qc * kLdk + 32 * half];
-            const double* wv = &S.w[32 * half];
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int k = 0; k < 32; k += 2) {
-                s0 = fma(fcol[k], wv[k], s0);
-                s1 = fma(fcol[k + 1], wv[k + 1], s1);
-            }
-            double sum = s0 + s1;
-            sum += __shfl_xor(sum, 1, 64);
-            if (half == 0) {
-                if (qc < 64) S.qx[qc] = cq + sum;
-                else S.qu[qc - 64] = cq + sum;
-            }
         }
         RIC_TICK(2)
         __syncthreads();
