@@ -461,19 +461,28 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         // reads of the later tiles and [qx; qu] = [cx; cu] + F'w (riccati.py:112-116: two lanes a column, 32 products
         // each; the lanes beyond the 160 that have a column run along on the last one).  In front of / behind the MFMAs
         // they cost the phase ~1.2k cycles a step.
+        // The operands themselves are streamed: a lane's 16 values of a tile column are eight 16-byte LDS reads, and read
+        // whole in front of the phase (qi, P, two tiles of F': 32 reads a wave, 128 KB a CU at 128 B a cycle) they held the
+        // first MFMA back ~1k cycles; now each pair is read a few slots before the MFMAs that use it.
         double dmax_t;
         {
-            double qi[16], Pc[16];
-            ld16(qi, S.X, col, g);             // elements (16 I + g + 4 r, col)
-            ld16(Pc, S.P, 16 * w + c, g);
-            ld16(fb0, S.F, c, g);
-            ld16(fb1, S.F, 16 + c, g);
+            // pair i (elements 2 i, 2 i + 1) of this lane's operands of column `colx` of an image - ld16() by pieces
+            auto pr = [&](const double* img, int colx, int i) {
+                return *reinterpret_cast<const r64_d2*>(img + colx * kLdk + 16 * g + 2 * i);
+            };
+            r64_d2 q2[8], Pc2[8], A0[8], A1[8], B0[8], B1[8], C0[8];
+            // in front: what the first MFMA of each chain needs - the tiles' starting values, pair 0 of the operands
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Q[e >> 2][e & 3] = qi[e];
+            for (int i = 0; i < 4; ++i) q2[i] = pr(S.X, col, i);   // elements (16 I + g + 4 r, col), I = 0, 1
+            Pc2[0] = pr(S.P, 16 * w + c, 0);
+            A0[0] = pr(S.F, c, 0);
+            A1[0] = pr(S.F, 16 + c, 0);
+            Q[0] = d4{q2[0][0], q2[0][1], q2[1][0], q2[1][1]};
+            Q[1] = d4{q2[2][0], q2[2][1], q2[3][0], q2[3][1]};
             double dm = 0.0, cm = 0.0, poison = 0.0, mi0 = 0.0, mi1 = 0.0;
             auto mirror = [&](int e) { return S.X[(16 * (e >> 2) + g + 4 * (e & 3)) * kLdk + pk(col)]; };   // (col, 16 I + g + 4 r)
             auto sym = [&](int e, double mi) {   // sym_lane(), one element
-                const double d = qi[e] - mi;
+                const double d = q2[e >> 1][e & 1] - mi;
                 dm = fmax(dm, fabs(d));
                 cm = fmax(cm, fabs(mi));
                 poison = fma(d, 0.0, poison);
@@ -485,28 +494,37 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             const r64_d2* wv = reinterpret_cast<const r64_d2*>(&S.w[32 * half]);
             double s0 = 0.0, s1 = 0.0;
             r64_d2 gf = {0.0, 0.0}, gw = {0.0, 0.0};
-            double fq[4];   // k = 16 w + 4 s + g of B's column c: position 16 g + 4 w + s
-            auto sideA = [&](int slot) {   // 32 slots under Q[0], Q[1]
+            r64_d2 fq2[2];   // k = 16 w + 4 s + g of B's column c: position 16 g + 4 w + s
+            auto sideA = [&](int slot) {   // 32 slots under Q[0], Q[1]; MFMA pair e = slot / 2 uses operand pair e / 2
                 // mirrors: read in slot e (two at a time in flight), compared two slots later
                 if (slot >= 2 && slot < 18) sym(slot - 2, (slot & 1) ? mi1 : mi0);
                 if (slot < 16) { if (slot & 1) mi1 = mirror(slot); else mi0 = mirror(slot); }
-                if (slot == 18) ld16(fb2, S.F, 32 + c, g);
-                if (slot == 22) ld16(fb3, S.F, 48 + c, g);
-                if (slot >= 26) {   // max |C| over the wave
-                    const int o = 32 >> (slot - 26);
+                if (slot < 4) q2[4 + slot] = pr(S.X, col, 4 + slot);   // the starting values of tiles 2, 3
+                if (slot < 28) {   // operand pair k + 1, four slots ahead of its MFMAs
+                    const int k = slot >> 2;
+                    if ((slot & 3) == 0) Pc2[k + 1] = pr(S.P, 16 * w + c, k + 1);
+                    if ((slot & 3) == 1) A0[k + 1] = pr(S.F, c, k + 1);
+                    if ((slot & 3) == 2) A1[k + 1] = pr(S.F, 16 + c, k + 1);
+                }
+                if (slot == 28) B0[0] = pr(S.F, 32 + c, 0);
+                if (slot == 29) B1[0] = pr(S.F, 48 + c, 0);
+                if (slot >= 20 && slot < 26) {   // max |C| over the wave
+                    const int o = 32 >> (slot - 20);
                     cm = fmax(cm, __shfl_xor(cm, o, 64));
                 }
+                if (slot == 27) { if (lane == 0) S.cmax[w] = cm; }
             };
             auto sideB = [&](int slot) {   // 32 slots under Q[2], Q[3]
-                if (slot == 0) { if (lane == 0) S.cmax[w] = cm; }
-                if (slot == 1) ld16(fb0, S.F, 64 + c, g);
-                if (slot == 3) {
-#pragma unroll
-                    for (int sq = 0; sq < 4; ++sq) fq[sq] = S.F[(64 + c) * kLdk + 16 * g + 4 * w + sq];
+                if (slot < 28) {
+                    const int k = slot >> 2;
+                    if ((slot & 3) == 0) B0[k + 1] = pr(S.F, 32 + c, k + 1);
+                    if ((slot & 3) == 1) B1[k + 1] = pr(S.F, 48 + c, k + 1);
                 }
-                // the q vectors: pair k of 16 read in slot 6 + k... and multiplied a slot later
-                if (slot >= 7 && slot < 23) { s0 = fma(gf[0], gw[0], s0); s1 = fma(gf[1], gw[1], s1); }
-                if (slot >= 6 && slot < 22) { gf = fcol[slot - 6]; gw = wv[slot - 6]; }
+                if ((slot & 3) == 2) C0[slot >> 2] = pr(S.F, 64 + c, slot >> 2);   // the Qux tile's operands, all eight pairs
+                if (slot == 3 || slot == 7) fq2[slot >> 2] = *reinterpret_cast<const r64_d2*>(&S.F[(64 + c) * kLdk + 16 * g + 4 * w + 2 * (slot >> 2)]);
+                // the q vectors: pair k of 16 read in slot 8 + k and multiplied a slot later
+                if (slot >= 9 && slot < 25) { s0 = fma(gf[0], gw[0], s0); s1 = fma(gf[1], gw[1], s1); }
+                if (slot >= 8 && slot < 24) { gf = fcol[slot - 8]; gw = wv[slot - 8]; }
             };
             if (!RIC_SPREAD) {
 #pragma unroll
@@ -514,27 +532,29 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {   // two independent accumulator chains at a time (see Ph1)
-                Q[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[e], Pc[e], Q[0], 0, 0, 0);
+                Q[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[e >> 1][e & 1], Pc2[e >> 1][e & 1], Q[0], 0, 0, 0);
                 if (RIC_SPREAD) { sideA(2 * e); __builtin_amdgcn_sched_barrier(0); }
-                Q[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[e], Pc[e], Q[1], 0, 0, 0);
+                Q[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[e >> 1][e & 1], Pc2[e >> 1][e & 1], Q[1], 0, 0, 0);
                 if (RIC_SPREAD) { sideA(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
             }
             dmax_t = dm + poison;
+            Q[2] = d4{q2[4][0], q2[4][1], q2[5][0], q2[5][1]};
+            Q[3] = d4{q2[6][0], q2[6][1], q2[7][0], q2[7][1]};
             if (!RIC_SPREAD) {
 #pragma unroll
                 for (int k = 0; k < 32; ++k) sideB(k);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                Q[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb2[e], Pc[e], Q[2], 0, 0, 0);
+                Q[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(B0[e >> 1][e & 1], Pc2[e >> 1][e & 1], Q[2], 0, 0, 0);
                 if (RIC_SPREAD) { sideB(2 * e); __builtin_amdgcn_sched_barrier(0); }
-                Q[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb3[e], Pc[e], Q[3], 0, 0, 0);
+                Q[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(B1[e >> 1][e & 1], Pc2[e >> 1][e & 1], Q[3], 0, 0, 0);
                 if (RIC_SPREAD) { sideB(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
             }
             double sum = s0 + s1;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                Q[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[e], Pc[e], Q[4], 0, 0, 0);
+                Q[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(C0[e >> 1][e & 1], Pc2[e >> 1][e & 1], Q[4], 0, 0, 0);
                 if (RIC_SPREAD) {
                     if (e == 0) sum += __shfl_xor(sum, 1, 64);
                     if (e == 2) {
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if ((e & 3) == 3) {
-                    qp = __builtin_amdgcn_mfma_f64_16x16x4f64(fq[e >> 2], Pw4[e >> 2], qp, 0, 0, 0);
+                    qp = __builtin_amdgcn_mfma_f64_16x16x4f64(fq2[e >> 3][(e >> 2) & 1], Pw4[e >> 2], qp, 0, 0, 0);
                     if (RIC_SPREAD) __builtin_amdgcn_sched_barrier(0);
                 }
             }
