@@ -356,11 +356,15 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 #pragma unroll
             for (int i = 0; i < 30; ++i) piece(i);
         }
-        double fb0[16], fb1[16];   // operand tiles, one ahead of the MFMAs
-        double fb2[16], fb3[16];
-        ld16(fb1, S.F, c, g);
-        ld16(fb0, S.F, 16 + c, g);
-        ld16(fb2, S.F, 80, g);      // the c_t column (every lane the same column): for w below
+        // The B operands (a lane's 16 values of a column of the F image: eight 16-byte LDS reads) are streamed, each pair
+        // read a few slots ahead of the MFMAs that use it (see Ph2).
+        auto prF = [&](int colx, int i) {   // pair i (elements 2 i, 2 i + 1) of this lane's operands of column colx
+            return *reinterpret_cast<const r64_d2*>(&S.F[colx * kLdk + 16 * g + 2 * i]);
+        };
+        r64_d2 T0[8], T1[8], T2[8], T3[8], TB[8], CC[8];
+        T0[0] = prF(c, 0);
+        T1[0] = prF(16 + c, 0);
+        CC[0] = prF(80, 0);         // the c_t column (every lane the same column): for w below
         // Two tiles at a time, their MFMAs alternating: a chain of 16 MFMAs on one accumulator leaves the matrix pipe
         // idle between dependent issues, two independent chains keep it busy.
         d4 Pw4, pa, pb;   // (pa, pb: finished tiles on their way to LDS)
@@ -375,12 +379,22 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             // front of the MFMAs it cost the phase ~600 cycles a step) and the operand reads of the next two tiles.
             double vc = 0.0;  // (V'c)[col] = sum_k V'[col][k] c[k], k = 16 kt + 4 s + g on this lane
             auto side = [&](int slot) {
-                if (slot < 16) vc = fma(Vt[slot >> 2][slot & 3], fb2[slot], vc);
-                else if (slot == 16) vc += __shfl_xor(vc, 16, 64);
-                else if (slot == 18) vc += __shfl_xor(vc, 32, 64);
-                else if (slot == 20) { if (g == 0) S.w[pk(col)] = fma(2.0, vc, vown); }
-                else if (slot == 22) ld16(fb2, S.F, 32 + c, g);
-                else if (slot == 26) ld16(fb3, S.F, 48 + c, g);
+                if (slot >= 2 && slot < 18) {
+                    const int el = slot - 2;
+                    vc = fma(Vt[el >> 2][el & 3], CC[el >> 1][el & 1], vc);
+                    asm volatile("" : "+v"(vc));
+                }
+                if (slot == 18) vc += __shfl_xor(vc, 16, 64);
+                if (slot == 20) vc += __shfl_xor(vc, 32, 64);
+                if (slot == 22) { if (g == 0) S.w[pk(col)] = fma(2.0, vc, vown); }
+                if (slot < 14 && (slot & 1) == 0) CC[(slot >> 1) + 1] = prF(80, (slot >> 1) + 1);
+                if (slot < 28) {   // operand pair k + 1, four slots ahead of its MFMAs
+                    const int k = slot >> 2;
+                    if ((slot & 3) == 0) T0[k + 1] = prF(c, k + 1);
+                    if ((slot & 3) == 1) T1[k + 1] = prF(16 + c, k + 1);
+                }
+                if (slot == 28) T2[0] = prF(32 + c, 0);
+                if (slot == 29) T3[0] = prF(48 + c, 0);
             };
             if (!RIC_SPREAD) {
 #pragma unroll
@@ -389,9 +403,9 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb1[e], a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T0[e >> 1][e & 1], a0, 0, 0, 0);
                 if (RIC_SPREAD) { piece(2 * e); side(2 * e); __builtin_amdgcn_sched_barrier(0); }
-                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb0[e], a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T1[e >> 1][e & 1], a1, 0, 0, 0);
                 if (RIC_SPREAD) { if (2 * e + 1 < 30) piece(2 * e + 1); side(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
             }
             pa = a0;
@@ -399,22 +413,28 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         }
         {
             // tiles 2, 3; in their shadow: the B block column's operands, the first two tiles' way to LDS
+            auto side = [&](int slot) {
+                if (slot < 28) {
+                    const int k = slot >> 2;
+                    if ((slot & 3) == 0) T2[k + 1] = prF(32 + c, k + 1);
+                    if ((slot & 3) == 1) T3[k + 1] = prF(48 + c, k + 1);
+                }
+                if ((slot & 3) == 2) TB[slot >> 2] = prF(64 + c, slot >> 2);
+                if (slot == 3) put_P(pa, 0);
+                if (slot == 7) put_P(pb, 1);
+            };
+            if (!RIC_SPREAD) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) side(k);
+            }
             d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb2[e], a0, 0, 0, 0);
-                if (RIC_SPREAD) {
-                    if (e == 0) ld16(fb1, S.F, 64 + c, g);
-                    if (e == 2) put_P(pa, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb3[e], a1, 0, 0, 0);
-                if (RIC_SPREAD) {
-                    if (e == 2) put_P(pb, 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T2[e >> 1][e & 1], a0, 0, 0, 0);
+                if (RIC_SPREAD) { side(2 * e); __builtin_amdgcn_sched_barrier(0); }
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T3[e >> 1][e & 1], a1, 0, 0, 0);
+                if (RIC_SPREAD) { side(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
             }
-            if (!RIC_SPREAD) { ld16(fb1, S.F, 64 + c, g); put_P(pa, 0); put_P(pb, 1); }
             pa = a0;
             pb = a1;
         }
@@ -424,7 +444,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], fb1[e], a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], TB[e >> 1][e & 1], a0, 0, 0, 0);
                 if (RIC_SPREAD) {
                     if (e == 1) put_P(pa, 2);
                     if (e >= 2) {
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[(e + 8) >> 2][(e + 8) & 3], fb1[e + 8], a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[(e + 8) >> 2][(e + 8) & 3], TB[(e + 8) >> 1][e & 1], a1, 0, 0, 0);
                 if (RIC_SPREAD) {
                     if (e == 1) put_P(pb, 3);
                     if (e >= 6) {
