@@ -339,8 +339,8 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         // cu element for the q vectors - threads 0..159, two per column; waves 0, 1: cx, wave 2: cu) are not needed before
         // Ph2 / Ph3.  The wave issues in order: what stands between two matrix-core instructions runs while the first one
         // occupies the pipe (64 cycles), what stands in front of the whole run of them does not - so the loads and their
-        // scalar address arithmetic are issued one at a time between the first 32 MFMAs (piece() below) instead of as a
-        // 230-instruction prologue.
+        // scalar address arithmetic are issued one at a time between the first 64 MFMAs (piece() below, every other slot)
+        // instead of as a 230-instruction prologue.
         const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane(t);
         const unsigned tp = (unsigned)__builtin_amdgcn_readfirstlane(t >= 1 ? t - 1 : 0);
         d4 Q[5];
@@ -404,9 +404,9 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T0[e >> 1][e & 1], a0, 0, 0, 0);
-                if (RIC_SPREAD) { piece(2 * e); side(2 * e); __builtin_amdgcn_sched_barrier(0); }
+                if (RIC_SPREAD) { side(2 * e); __builtin_amdgcn_sched_barrier(0); }
                 a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T1[e >> 1][e & 1], a1, 0, 0, 0);
-                if (RIC_SPREAD) { if (2 * e + 1 < 30) piece(2 * e + 1); side(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
+                if (RIC_SPREAD) { piece(e); side(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }   // (the odd slots are the lighter ones)
             }
             pa = a0;
             pb = a1;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
                 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T2[e >> 1][e & 1], a0, 0, 0, 0);
                 if (RIC_SPREAD) { side(2 * e); __builtin_amdgcn_sched_barrier(0); }
                 a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T3[e >> 1][e & 1], a1, 0, 0, 0);
-                if (RIC_SPREAD) { side(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
+                if (RIC_SPREAD) { if (16 + e < 30) piece(16 + e); side(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
             }
             pa = a0;
             pb = a1;
