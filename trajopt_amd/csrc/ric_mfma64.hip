@@ -733,17 +733,27 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             bad = t;
             break;
         }
+        {
+            // all sixteen A operands (-Z) first: read one at a time in front of its MFMA, each exposed the LDS latency
+            double ka[16];
 #pragma unroll
-        for (int I = 0; I < 4; ++I)
+            for (int I = 0; I < 4; ++I)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) ka[4 * I + s] = S.K[(4 * s + g) + kLd16 * (16 * I + c)];
+            const double zq0 = S.zq[g], zq1 = S.zq[g + 4], zq2 = S.zq[g + 8], zq3 = S.zq[g + 12], qxc = S.qx[colok ? col : 0];
+            __builtin_amdgcn_sched_barrier(0);
+            // four independent accumulators: s outermost, so that no MFMA waits for the one before it
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.K[(4 * s + g) + kLd16 * (16 * I + c)], Q[4][s], Q[I], 0, 0, 0);
-        {
-            double part = 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part = fma(Q[4][r], S.zq[g + 4 * r], part);   // (Y' zq)[col]
+                for (int I = 0; I < 4; ++I)
+                    Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(ka[4 * I + s], Q[4][s], Q[I], 0, 0, 0);
+            double part = fma(Q[4][0], zq0, 0.0);   // (Y' zq)[col]
+            part = fma(Q[4][1], zq1, part);
+            part = fma(Q[4][2], zq2, part);
+            part = fma(Q[4][3], zq3, part);
             part = xor_sum16(part);
-            vown = colok ? S.qx[col] - part : 0.0;  // v = qx + 2 Qux' kff = qx - Qux' Quu^-1 qu   (riccati.py:124)
+            vown = colok ? qxc - part : 0.0;  // v = qx + 2 Qux' kff = qx - Qux' Quu^-1 qu   (riccati.py:124)
         }
 #pragma unroll
         for (int I = 0; I < 4; ++I)
