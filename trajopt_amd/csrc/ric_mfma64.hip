@@ -121,6 +121,10 @@ __device__ __forceinline__ void r64_st(double x, __amdgpu_buffer_rsrc_t r, unsig
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(r64_v2u, x), r, off, 0, 0);
 }
 
+__device__ __forceinline__ void r64_st_s(double x, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {   // range check on voff alone
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(r64_v2u, x), r, voff, soff, 0);
+}
+
 __device__ __forceinline__ double bcast_lane(double x, int lane) {  // lane is wave-uniform
     int lo = __double2loint(x), hi = __double2hiint(x);
     lo = __builtin_amdgcn_readlane(lo, lane);
@@ -332,6 +336,31 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             xs[jj] = r64_ld(rCxx, (16 * wu + jj) < n ? voRow : kR64NoStore, (tu * (unsigned)nn + (unsigned)(n * (16 * wu + jj))) * 8u);
     };
     fetch_X(T - 1);
+    // The outputs of a step are stored one piece a slot from the shadows of the NEXT step's Ph1 (Vt, vown and the LDS
+    // images of K, kff stand unchanged until that step's Ph3 / Ph4) - behind the V update they cost Ph4 ~1.5k cycles a step
+    // with nothing to overlap.  Piece j < 16: element (16 I + g + 4 r, col) of V, j = 4 I + r, stored along the contiguous
+    // index (V' = V); 16..19: four gains a thread; 20: v; 21: kff.  `have` = there is such a step (not in the first
+    // iteration, whose "previous step" is the terminal slice stored above).
+    unsigned okbits = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) okbits |= (colok && (16 * (j >> 2) + g + 4 * (j & 3)) < n) ? (1u << j) : 0u;
+    const unsigned voV0 = (unsigned)(col + n * g) * 8u;
+    constexpr int kOutPieces = 22;
+    auto out_piece = [&](int j, unsigned tt, bool have) {
+        if (j < 16) {
+            const bool okv = have && ((okbits >> j) & 1u);
+            r64_st_s(Vt[j >> 2][j & 3], rV, okv ? voV0 : kR64NoStore, (tt * (unsigned)nn + (unsigned)(n * (16 * (j >> 2) + 4 * (j & 3)))) * 8u);
+        } else if (j < 20) {   // dx du <= 1024 gains: four per thread
+            const int idx = tid + 256 * (j - 16);
+            const bool okk = idx < (int)nm;
+            const int i = okk ? idx % m : 0, jj = okk ? idx / m : 0;
+            r64_st_s(S.Ko[i + kLd16 * jj], rK, (okk && have) ? (unsigned)idx * 8u : kR64NoStore, tt * (unsigned)nm * 8u);
+        } else if (j == 20) {
+            r64_st_s(vown, rv_, (g == 0 && colok && have) ? (unsigned)col * 8u : kR64NoStore, tt * (unsigned)n * 8u);
+        } else {
+            r64_st_s(S.kff[tid < m ? tid : 0], rkff, (tid < m && have) ? (unsigned)tid * 8u : kR64NoStore, tt * (unsigned)m * 8u);
+        }
+    };
     for (int t = T - 1; t >= 0; --t) {
         // ================= Ph1: prefetch, w = 2 V'c + v', P = V' F ==========================================
         // This phase's 30 global loads (F_{t-1}: 21; the Qux tile's start Cxu', riccati.py:110: element (i, col) =
@@ -343,6 +372,8 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         // instead of as a 230-instruction prologue.
         const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane(t);
         const unsigned tp = (unsigned)__builtin_amdgcn_readfirstlane(t >= 1 ? t - 1 : 0);
+        const unsigned tn = (unsigned)__builtin_amdgcn_readfirstlane(t + 1);   // the step whose outputs go out under this Ph1
+        const bool have_out = t < T - 1;
         d4 Q[5];
         d4 qp;
         double cq;
@@ -355,6 +386,8 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         if (!RIC_SPREAD) {
 #pragma unroll
             for (int i = 0; i < 30; ++i) piece(i);
+#pragma unroll
+            for (int j = 0; j < kOutPieces; ++j) out_piece(j, tn, have_out);
         }
         // The B operands (a lane's 16 values of a column of the F image: eight 16-byte LDS reads) are streamed, each pair
         // read a few slots ahead of the MFMAs that use it (see Ph2).
@@ -404,7 +437,13 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T0[e >> 1][e & 1], a0, 0, 0, 0);
-                if (RIC_SPREAD) { side(2 * e); __builtin_amdgcn_sched_barrier(0); }
+                if (RIC_SPREAD) {
+                    side(2 * e);
+                    if (e == 10) out_piece(21, tn, have_out);
+                    if (e == 11) out_piece(20, tn, have_out);
+                    if (e >= 12) out_piece(16 + (e - 12), tn, have_out);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T1[e >> 1][e & 1], a1, 0, 0, 0);
                 if (RIC_SPREAD) { piece(e); side(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }   // (the odd slots are the lighter ones)
             }
@@ -431,7 +470,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T2[e >> 1][e & 1], a0, 0, 0, 0);
-                if (RIC_SPREAD) { side(2 * e); __builtin_amdgcn_sched_barrier(0); }
+                if (RIC_SPREAD) { side(2 * e); out_piece(e, tn, have_out); __builtin_amdgcn_sched_barrier(0); }
                 a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T3[e >> 1][e & 1], a1, 0, 0, 0);
                 if (RIC_SPREAD) { if (16 + e < 30) piece(16 + e); side(2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
             }
@@ -758,24 +797,13 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 #pragma unroll
         for (int I = 0; I < 4; ++I)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rw = 16 * I + g + 4 * r;
-                const bool okv = colok && rw < n;
-                const double x = okv ? Q[I][r] : 0.0;  // padding stays exactly zero
-                Vt[I][r] = x;
-                // V' = V: stored along the contiguous index
-                r64_st(x, rV, okv ? (unsigned)((nn * (size_t)t + col + (size_t)n * rw) * 8) : kR64NoStore);
-            }
-        r64_st(vown, rv_, (g == 0 && colok) ? (unsigned)(((size_t)n * t + col) * 8) : kR64NoStore);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {   // dx du <= 1024 gains: four per thread
-            const int idx = tid + 256 * s4;
-            const bool okk = idx < (int)nm;
-            const int i = okk ? idx % m : 0, j = okk ? idx / m : 0;
-            r64_st(S.Ko[i + kLd16 * j], rK, okk ? (unsigned)((nm * (size_t)t + idx) * 8) : kR64NoStore);
-        }
-        r64_st(S.kff[tid < m ? tid : 0], rkff, tid < m ? (unsigned)(((size_t)m * t + tid) * 8) : kR64NoStore);
+            for (int r = 0; r < 4; ++r) Vt[I][r] = ((okbits >> (4 * I + r)) & 1u) ? Q[I][r] : 0.0;  // padding stays exactly zero
+        // (the step's outputs - V, v, K, kff - are stored from the shadows of the NEXT step's Ph1: out_piece())
         RIC_TICK(6)
+    }
+    if (bad < 0) {   // the outputs of step 0
+#pragma unroll
+        for (int j = 0; j < kOutPieces; ++j) out_piece(j, 0u, true);
     }
 #if RIC_DIAG
     if (tid == 0)
