@@ -144,10 +144,14 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// FULL: dx = 64, du = 16 (C5) known at compile time - every padding predicate, lane mask and offset product of the time
+// loop folds away (as run-time values their masks lived in ~40 scalar registers, spilled to lanes of a vector register and
+// read back inside the matrix-core slots); the other instantiation takes any 16 < dx <= 64, du <= 16.
+template <bool FULL>
 __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Ric64Lds& S = *reinterpret_cast<Ric64Lds*>(smem_raw);
-    const int n = a.n, m = a.m, T = a.T;
+    const int n = FULL ? 64 : a.n, m = FULL ? 16 : a.m, T = a.T;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const size_t p = blockIdx.x;
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
@@ -836,9 +840,13 @@ int launch_riccati_mfma64(const double* Cxx, const double* cx, const double* Cuu
     *handled = true;
     Ric64Args a{Cxx, cx, Cuu, cu, Cxu, A, B, c, V, v, K, kff, status, redo, n, m, T};
     const size_t lds = sizeof(Ric64Lds);
-    TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)ric_mfma64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds));
-    hipLaunchKernelGGL(ric_mfma64_kernel, dim3((unsigned)NP), dim3(256), lds, st, a);
+    if (n == 64 && m == 16) {
+        TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)ric_mfma64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ric_mfma64_kernel<true>, dim3((unsigned)NP), dim3(256), lds, st, a);
+    } else {
+        TRAJOPT_HIP_CHECK(hipFuncSetAttribute((const void*)ric_mfma64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ric_mfma64_kernel<false>, dim3((unsigned)NP), dim3(256), lds, st, a);
+    }
     TRAJOPT_HIP_CHECK(hipGetLastError());
     // the flagged problems, by the kernel without those assumptions (a workgroup of an unflagged problem leaves at once)
     return launch_riccati_wg(Cxx, cx, Cuu, cu, Cxu, A, B, c, n, m, T, NP, TRAJOPT_LAYOUT_PROBLEM_MAJOR, V, v, K, kff, status, st, status ? status : redo);
