@@ -191,12 +191,12 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const int idx = tid + 256 * s;
-        offA[s] = idx < (int)nn ? (idx / n) * kLdk + pk(idx % n) : kPark;
+        offA[s] = (FULL || idx < (int)nn) ? (idx / n) * kLdk + pk(idx % n) : kPark;
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int idx = tid + 256 * s;
-        offB[s] = idx < (int)nm ? (64 + idx / n) * kLdk + pk(idx % n) : kPark;
+        offB[s] = (FULL || idx < (int)nm) ? (64 + idx / n) * kLdk + pk(idx % n) : kPark;
     }
     const int offc = tid < n ? 80 * kLdk + pk(tid) : kPark;
     // Every load of the time loop is  descriptor of the problem's array + loop-invariant lane offset (VGPR) + scalar
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 
     // ---- terminal condition (riccati.py:104-105): block column w of V, own segment of v ----------------------
     const int col = 16 * w + c;          // the state index this lane owns as a column
-    const bool colok = col < n;
+    const bool colok = FULL || col < n;   // (FULL: a block of 256 threads covers exactly the 64 columns)
     // lane offsets of the cost inputs: element (row, col) of this lane's block column read along the contiguous index,
     // i.e. as C[col][row] (voT) - and, for the symmetry check, as it stands (voS); padding lanes pass the dropped offset
     unsigned voT[16], voS[16], voXu[4], voUu[4];
@@ -247,17 +247,17 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * I + g + 4 * r;
-            const bool ok = colok && row < n;
+            const bool ok = colok && (FULL || row < n);
             voT[4 * I + r] = ok ? (unsigned)(col + n * row) * 8u : kR64NoStore;
             voS[4 * I + r] = ok ? (unsigned)(row + n * col) * 8u : kR64NoStore;
         }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = g + 4 * r;
-        voXu[r] = (colok && i < m) ? (unsigned)(col + n * i) * 8u : kR64NoStore;
+        voXu[r] = (colok && (FULL || i < m)) ? (unsigned)(col + n * i) * 8u : kR64NoStore;
         voUu[r] = (w == 0 && i < m && c < m) ? (unsigned)(i + m * c) * 8u : kR64NoStore;
     }
-    const unsigned voRow = lane < n ? (unsigned)lane * 8u : kR64NoStore;
+    const unsigned voRow = (FULL || lane < n) ? (unsigned)lane * 8u : kR64NoStore;
     unsigned vocq;
     {
         const int qc = tid >> 1, el = qc < 64 ? qc : qc - 64, ne = qc < 64 ? n : m;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane(t);
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj)
-            xs[jj] = r64_ld(rCxx, (16 * wu + jj) < n ? voRow : kR64NoStore, (tu * (unsigned)nn + (unsigned)(n * (16 * wu + jj))) * 8u);
+            xs[jj] = r64_ld(rCxx, (FULL || (16 * wu + jj) < n) ? voRow : kR64NoStore, (tu * (unsigned)nn + (unsigned)(n * (16 * wu + jj))) * 8u);
     };
     fetch_X(T - 1);
     // The outputs of a step are stored one piece a slot from the shadows of the NEXT step's Ph1 (Vt, vown and the LDS
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
     // iteration, whose "previous step" is the terminal slice stored above).
     unsigned okbits = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) okbits |= (colok && (16 * (j >> 2) + g + 4 * (j & 3)) < n) ? (1u << j) : 0u;
+    for (int j = 0; j < 16; ++j) okbits |= (colok && (FULL || (16 * (j >> 2) + g + 4 * (j & 3)) < n)) ? (1u << j) : 0u;
     const unsigned voV0 = (unsigned)(col + n * g) * 8u;
     constexpr int kOutPieces = 22;
     auto out_piece = [&](int j, unsigned tt, bool have) {
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             r64_st_s(Vt[j >> 2][j & 3], rV, okv ? voV0 : kR64NoStore, (tt * (unsigned)nn + (unsigned)(n * (16 * (j >> 2) + 4 * (j & 3)))) * 8u);
         } else if (j < 20) {   // dx du <= 1024 gains: four per thread
             const int idx = tid + 256 * (j - 16);
-            const bool okk = idx < (int)nm;
+            const bool okk = FULL || idx < (int)nm;
             const int i = okk ? idx % m : 0, jj = okk ? idx / m : 0;
             r64_st_s(S.Ko[i + kLd16 * jj], rK, (okk && have) ? (unsigned)idx * 8u : kR64NoStore, tt * (unsigned)nm * 8u);
         } else if (j == 20) {
