@@ -365,6 +365,25 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             r64_st_s(S.kff[tid < m ? tid : 0], rkff, (tid < m && have) ? (unsigned)tid * 8u : kR64NoStore, tt * (unsigned)m * 8u);
         }
     };
+    // Block back substitution W = U^-1 Z (U unit upper, this wave's copy in S.U): rows of block j are final once the blocks
+    // right of it have been applied; A[row c][k-index g] = U(c, 4 j + g) for the rows c above block j.  K = -W,
+    // kff = -1/2 U^-1 zq (riccati.py:120-121).  Only the OUTPUTS need them, so the three steps (two dependent MFMAs each)
+    // and the hand-over to LDS are spread over the first slots of the next step's Ph1; the stores follow in its Ph2.
+    d4 Zt = {0.0, 0.0, 0.0, 0.0}, Zq4 = {0.0, 0.0, 0.0, 0.0};
+    auto back_sub = [&](int j) {
+        const double u = S.U[w][c + kLd16 * (4 * j + g)];
+        const double nU = (c < 4 * j) ? -u : 0.0;
+        Zt = __builtin_amdgcn_mfma_f64_16x16x4f64(nU, Zt[j], Zt, 0, 0, 0);
+        Zq4 = __builtin_amdgcn_mfma_f64_16x16x4f64(nU, Zq4[j], Zq4, 0, 0, 0);
+    };
+    auto gains_to_lds = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S.Ko[(g + 4 * r) + kLd16 * col] = -Zt[r];
+        if (w == 1 && c == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S.kff[g + 4 * r] = -0.5 * Zq4[r];
+        }
+    };
     for (int t = T - 1; t >= 0; --t) {
         // ================= Ph1: prefetch, w = 2 V'c + v', P = V' F ==========================================
         // This phase's 30 global loads (F_{t-1}: 21; the Qux tile's start Cxu', riccati.py:110: element (i, col) =
@@ -391,7 +410,12 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
 #pragma unroll
             for (int i = 0; i < 30; ++i) piece(i);
 #pragma unroll
-            for (int j = 0; j < kOutPieces; ++j) out_piece(j, tn, have_out);
+            for (int j = 0; j < 16; ++j) out_piece(j, tn, have_out);
+            out_piece(20, tn, have_out);
+            back_sub(3);
+            back_sub(2);
+            back_sub(1);
+            gains_to_lds();
         }
         // The B operands (a lane's 16 values of a column of the F image: eight 16-byte LDS reads) are streamed, each pair
         // read a few slots ahead of the MFMAs that use it (see Ph2).
@@ -443,9 +467,11 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
                 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T0[e >> 1][e & 1], a0, 0, 0, 0);
                 if (RIC_SPREAD) {
                     side(2 * e);
-                    if (e == 10) out_piece(21, tn, have_out);
+                    if (e == 1) back_sub(3);
+                    if (e == 4) back_sub(2);
+                    if (e == 7) back_sub(1);
+                    if (e == 10) gains_to_lds();
                     if (e == 11) out_piece(20, tn, have_out);
-                    if (e >= 12) out_piece(16 + (e - 12), tn, have_out);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[e >> 2][e & 3], T1[e >> 1][e & 1], a1, 0, 0, 0);
@@ -619,6 +645,8 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             for (int e = 0; e < 16; ++e) {
                 Q[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(C0[e >> 1][e & 1], Pc2[e >> 1][e & 1], Q[4], 0, 0, 0);
                 if (RIC_SPREAD) {
+                    if (e >= 4 && e < 8) out_piece(16 + (e - 4), tn, have_out);   // last step's gains (in LDS since Ph1)
+                    if (e == 8) out_piece(21, tn, have_out);
                     if (e == 0) sum += __shfl_xor(sum, 1, 64);
                     if (e == 2) {
                         if (tid < 160 && half == 0) {
@@ -634,6 +662,9 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
                 }
             }
             if (!RIC_SPREAD) {
+#pragma unroll
+                for (int j = 16; j < 20; ++j) out_piece(j, tn, have_out);
+                out_piece(21, tn, have_out);
                 sum += __shfl_xor(sum, 1, 64);
                 if (tid < 160 && half == 0) {
                     if (qcol < 64) S.qx[qcol] = cq + sum;
@@ -666,7 +697,7 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         // after which R = Y = L^-1 Qux(:, w) and the rows X' are the unit upper factor U = L'.  Ph4 needs only Y and Z;
         // the gains come from the block back substitution K = -U^-1 Z (three more instructions per tile).
         bool ok = true;
-        d4 Sd, Rq = {0.0, 0.0, 0.0, 0.0}, Zt, Zq4;
+        d4 Sd, Rq = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = g + 4 * r;
@@ -747,25 +778,11 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             bad = t;
             break;
         }
-        const d4 zqf = Zq4;   // zq = D^-1 L^-1 qu: what v needs (Ph4), before the back substitution turns it into Quu^-1 qu
-        // block back substitution W = U^-1 Z (U unit upper): rows of block j are final once the blocks right of it have
-        // been applied; A[row c][k-index g] = U(c, 4 j + g) for the rows c above block j
-        wave_fence();
-#pragma unroll
-        for (int j = 3; j >= 1; --j) {
-            const double u = S.U[w][c + kLd16 * (4 * j + g)];
-            const double nU = (c < 4 * j) ? -u : 0.0;
-            Zt = __builtin_amdgcn_mfma_f64_16x16x4f64(nU, Zt[j], Zt, 0, 0, 0);
-            Zq4 = __builtin_amdgcn_mfma_f64_16x16x4f64(nU, Zq4[j], Zq4, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S.Ko[(g + 4 * r) + kLd16 * col] = -Zt[r];               // K = -Quu^-1 Qux  (riccati.py:120)
+        // zq = D^-1 L^-1 qu is what v needs (Ph4); the back substitution that turns Z, zq into the gains is not on the
+        // value recursion's path: it rides in the next step's Ph1 (back_sub() there)
         if (w == 1 && c == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                S.kff[g + 4 * r] = -0.5 * Zq4[r];                                         // kff = -1/2 Quu^-1 qu (riccati.py:121)
-                S.zq[g + 4 * r] = zqf[r];
-            }
+            for (int r = 0; r < 4; ++r) S.zq[g + 4 * r] = Zq4[r];
         }
         RIC_TICK(4)
         __syncthreads();
@@ -805,7 +822,12 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
         // (the step's outputs - V, v, K, kff - are stored from the shadows of the NEXT step's Ph1: out_piece())
         RIC_TICK(6)
     }
-    if (bad < 0) {   // the outputs of step 0
+    if (bad < 0) {   // the outputs of step 0 (block-uniform)
+        back_sub(3);
+        back_sub(2);
+        back_sub(1);
+        gains_to_lds();
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < kOutPieces; ++j) out_piece(j, 0u, true);
     }
