@@ -685,8 +685,27 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             const double tol = 1e-13 * fmax(fmax(S.cmax[0], S.cmax[1]), fmax(S.cmax[2], S.cmax[3]));
             if (!(dmax_t <= tol)) S.asym = 1;   // read by everybody behind the next barrier
         }
-        stage_F();  // the F image of this step is dead: bring in step t - 1
-        fetch_X(t >= 1 ? t - 1 : 0);   // (unconditional: the last one is a harmless re-load)
+        // The F image of this step is dead: step t - 1 moves in, and the slice of Cxx for it is requested (unconditional: the
+        // last one is a harmless re-load) - both in pieces, inside the waits of the elimination below (stage_chunk() behind
+        // the broadcast read of a pivot block, fetch_X_chunk() behind its first three MFMAs); in front of the chain they cost it
+        // ~500 cycles.
+        const unsigned tq = (unsigned)__builtin_amdgcn_readfirstlane(t >= 1 ? t - 1 : 0);
+        auto stage_chunk = [&](int i) {   // 21 LDS stores in three chunks
+#pragma unroll
+            for (int s7 = 0; s7 < 7; ++s7) {
+                const int q = 7 * i + s7;
+                if (q < 16) S.F[offA[q]] = fA[q];
+                else if (q < 20) S.F[offB[q - 16]] = fB[q - 16];
+                else S.F[offc] = fc;
+            }
+        };
+        auto fetch_X_chunk = [&](int i) {   // 16 loads in four chunks
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const int jj = 4 * i + j4;
+                xs[jj] = r64_ld(rCxx, (FULL || (16 * wu + jj) < n) ? voRow : kR64NoStore, (tq * (unsigned)nn + (unsigned)(n * (16 * wu + jj))) * 8u);
+            }
+        };
         // Quu = L D L' with 4 x 4 blocks (L unit lower BLOCK triangular, D block diagonal), no pivoting: a non-positive
         // scalar pivot inside a block flags the problem for the generic kernel.  In the matrix cores' D layout register
         // r of a 16 x 16 tile holds rows 4 r + g - i.e. ROW BLOCK r - and, for a symmetric tile, that register is at
@@ -724,6 +743,11 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
                 }
             }
             wave_fence();
+            if (k < 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage_chunk(k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // Pi = P^-1 by 2 x 2 blocks, P = [A B'; B C] (lower triangle of P used, P(a, b) at a + 4 b):
             //   A^-1 = adj(A) / det A,  S = C - B A^-1 B',  S^-1 = adj(S) / det S,
             //   Pi = [A^-1 + G' S^-1 G, -G' S^-1; -S^-1 G, S^-1],  G = B A^-1
@@ -764,11 +788,17 @@ __global__ __launch_bounds__(256) void ric_mfma64_kernel(Ric64Args a) {
             const d4 Xs = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, Sd[k], zero4, 0, 0, 0);   // rows 0..3: X' = Pi Quu(blk, :)
             const d4 Zr = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, R[k], zero4, 0, 0, 0);    // rows 0..3: Z_k = Pi Y_k
             const d4 Zv = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, Rq[k], zero4, 0, 0, 0);   // rows 0..3, column 0: zq_k
-            // columns of the block, rows below it (by symmetry register k again), negated: the rank-4 downdates
-            const double nA = (c >= 4 * (k + 1)) ? -Sd[k] : 0.0;
-            Sd = __builtin_amdgcn_mfma_f64_16x16x4f64(nA, Xs[0], Sd, 0, 0, 0);
-            R = __builtin_amdgcn_mfma_f64_16x16x4f64(nA, Zr[0], R, 0, 0, 0);
-            Rq = __builtin_amdgcn_mfma_f64_16x16x4f64(nA, Zv[0], Rq, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_X_chunk(k);
+            __builtin_amdgcn_sched_barrier(0);
+            // columns of the block, rows below it (by symmetry register k again), negated: the rank-4 downdates (below the
+            // last block there is nothing)
+            if (k < 3) {
+                const double nA = (c >= 4 * (k + 1)) ? -Sd[k] : 0.0;
+                Sd = __builtin_amdgcn_mfma_f64_16x16x4f64(nA, Xs[0], Sd, 0, 0, 0);
+                R = __builtin_amdgcn_mfma_f64_16x16x4f64(nA, Zr[0], R, 0, 0, 0);
+                Rq = __builtin_amdgcn_mfma_f64_16x16x4f64(nA, Zv[0], Rq, 0, 0, 0);
+            }
             Zt[k] = Zr[0];
             Zq4[k] = Zv[0];
             S.U[w][(4 * k + g) + kLd16 * c] = Xs[0];           // row 4 k + g of U (its entries right of the block are used)
