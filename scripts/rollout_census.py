@@ -17,11 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from trajopt_amd import _lib  # noqa: E402
 
-# <SYS, MINOR, KMINOR (the gains' layout in the driver: PROBLEM_MINOR for dx <= 6), FAST, TB, UNR>
-KERNELS = {"cartpole": "rollout_kernelINS_7SysPhysILi2EEELb1ELb1ELb1ELb1ELb1ELb0EEEvNS_11RolloutArgsE",
-           "pendulum": "rollout_kernelINS_7SysPhysILi1EEELb1ELb1ELb1ELb1ELb1ELb0EEEvNS_11RolloutArgsE",
-           "double_cartpole": "rollout_kernelINS_7SysPhysILi3EEELb1ELb1ELb1ELb1ELb1ELb0EEEvNS_11RolloutArgsE",
-           "quadrotor": "rollout_kernelINS_7SysPhysILi5EEELb1ELb0ELb1ELb1ELb1ELb0EEEvNS_11RolloutArgsE"}
+# <SYS, MINOR, KMINOR (the gains' layout in the driver: PROBLEM_MINOR for dx <= 6), FAST, TB, UNR, CO, KL>
+KERNELS = {"cartpole": "rollout_kernelINS_7SysPhysILi2EEELb1ELb1ELb1ELb1ELb1ELb0ELb0EEEvNS_11RolloutArgsE",
+           "pendulum": "rollout_kernelINS_7SysPhysILi1EEELb1ELb1ELb1ELb1ELb1ELb0ELb0EEEvNS_11RolloutArgsE",
+           "double_cartpole": "rollout_kernelINS_7SysPhysILi3EEELb1ELb1ELb1ELb1ELb1ELb0ELb0EEEvNS_11RolloutArgsE",
+           # dx + du > 8: half-block stage, gains through LDS (KL), PROBLEM_MAJOR gains
+           "quadrotor": "rollout_kernelINS_7SysPhysILi5EEELb1ELb0ELb1ELb1ELb0ELb0ELb1EEEvNS_11RolloutArgsE"}
+# steps of the time loop in one trip of the counted loop: 8 for the straight-line form, 4 for the half-block form
+STEPS_PER_TRIP = {"quadrotor": 4}
 
 
 ROLLOUT_SOURCES = _lib.ROLLOUT_SOURCES
@@ -42,11 +45,12 @@ def main():
             loops = json.load(open(js))["loops"]
             # the largest loop closed by a conditional branch = the block loop (8 straight-line steps)
             big = max((l for l in loops if l["conditional"]), key=lambda l: l["instructions"])
-            per_step = {k: v / 8.0 for k, v in big["by_category"].items()}
-            res["kernels"][env] = {"mangled": key, "trip_instructions": big["instructions"],
-                                   "instructions_per_step": big["instructions"] / 8.0,
-                                   "valu_per_step": big["valu"] / 8.0,
-                                   "fp64_flops_per_lane_step": big["fp64_flops_per_lane"] / 8.0,
+            spt = float(STEPS_PER_TRIP.get(env, 8))
+            per_step = {k: v / spt for k, v in big["by_category"].items()}
+            res["kernels"][env] = {"mangled": key, "trip_instructions": big["instructions"], "steps_per_trip": spt,
+                                   "instructions_per_step": big["instructions"] / spt,
+                                   "valu_per_step": big["valu"] / spt,
+                                   "fp64_flops_per_lane_step": big["fp64_flops_per_lane"] / spt,
                                    "per_step_by_category": per_step}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: (v["instructions_per_step"], v["fp64_flops_per_lane_step"]) for k, v in res["kernels"].items()}))

@@ -79,45 +79,46 @@ template <int K> __device__ __forceinline__ Dual<K> operator/(const Dual<K>& a, 
 
 // sin and cos together.  fp64 issue slots are what these kernels pay for (one fp64 op per ~5 cycles per SIMD; the
 // library sincos is ~85 of them plus a Payne-Hanek path whose registers and branches sit in the hot loop).
-// Here: 3-term Cody-Waite reduction by pi/2 (k * pio2_1 is exact for |k| < 2^20: 33 + 20 bits) and the fdlibm
-// minimax kernels on |r| <= pi/4: absolute error ~1.5e-16, ~30 instructions.  Arguments in [2^20, 1e15) (only
-// rollouts that have already blown up reach them) are first folded by 2 pi with a two-term constant, which
-// costs accuracy proportional to |x| (|x| * 2e-16).  Beyond 1e15 the fold has no correct bits left (and the quadrant
-// conversion below would overflow an int): the result is NaN, as for inf / NaN - the reference's libm sin / cos stay
-// bounded there, so such a candidate's return is a huge finite number for the reference and NaN here; both reject it
-// in the line search (ilqr.py:196 compares false), and init_select_kernel refuses a non-finite return.
+// Here, 27 instructions and no branch:
+//  * reduction by pi, k = rint(x / pi) taken from a magic-number add (the integer sits in the low mantissa bits, its
+//    parity is bit 0 of the low word), r = x - k pi with a three-term Cody-Waite constant.  Each term is one FMA, and
+//    the FMA is what lifts fdlibm's |x| < 2^20 pi/2 limit: k * pi_1 (33-bit constant) need not be representable, only
+//    x - k pi_1 must be, and it is (it spans 2^-32 .. 2^21 for |k| < 2^51).  Measured against long double on 2 M random
+//    arguments per decade: absolute error <= 4.3e-16 up to |x| = 1e12, 6e-16 at 1e15 (scripts/debug/sincos_check.c);
+//    beyond 2^51 pi the result is meaningless (finite garbage, then inf / NaN), as it is for inf / NaN arguments - such
+//    a candidate has left every state bound long before and its return loses the line search either way
+//    (ilqr.py:196 compares false on NaN, init_select_kernel refuses a non-finite return);
+//  * on |r| <= pi/2 the fdlibm minimax kernels are evaluated at the HALF angle (their range is pi/4; the coefficients
+//    below are fdlibm's divided by powers of four, i.e. exact, so that the polynomials take w = r^2 directly) and the
+//    double-angle identities give sin r = 2 sin(r/2) cos(r/2), cos r = 1 - 2 sin^2(r/2): three more multiplications,
+//    but both results share ONE sign, (-1)^k - no quadrant swap (four 32-bit selects), no second flip mask.
+// Round 3: this form replaced reduction by pi/2 + swap + two flips + a ballot-guarded big-argument path (34
+// instructions and a branch per call, absolute error 1.7e-16).
 __device__ __forceinline__ void sincos_g(double x, double& s, double& c) {
-    const bool big = !(fabs(x) < 1048576.0);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(big) != 0, 0)) {   // one scalar branch for the whole wave
-        const double k2 = rint(x * 1.59154943091895345554e-01);        // 1 / (2 pi)
-        const double xf = fma(-k2, 2.44929359829470641435e-16, fma(-k2, 6.28318530717958623200e+00, x));
-        x = big ? (fabs(x) < 1e15 ? xf : __builtin_nan("")) : x;
-    }
-    const double fk = rint(x * 6.36619772367581382433e-01);
-    double r = fma(-fk, 1.57079632673412561417e+00, x);
-    r = fma(-fk, 6.07710050630396597660e-11, r);
-    r = fma(-fk, 2.02226624879595063154e-21, r);
-    const double z = r * r;
-    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    ps = fma(z, ps, 2.75573137070700676789e-06);
-    pc = fma(z, pc, -2.75573143513906633035e-07);
-    ps = fma(z, ps, -1.98412698298579493134e-04);
-    pc = fma(z, pc, 2.48015872894767294178e-05);
-    ps = fma(z, ps, 8.33333333332248946124e-03);
-    pc = fma(z, pc, -1.38888888888741095749e-03);
-    ps = fma(z, ps, -1.66666666666666324348e-01);
-    pc = fma(z, pc, 4.16666666666666019037e-02);
-    const double sr = fma(r * z, ps, r);
-    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
-    // quadrant: swap for odd q, then flip the sign bits - integer ops on the high words, no fp64 selects of negations
-    const int q = (int)fk;
-    const bool odd = (q & 1) != 0;
-    const double s0 = odd ? cr : sr, c0 = odd ? sr : cr;
-    const unsigned sflip = ((unsigned)q << 30) & 0x80000000u;          // q & 2
-    const unsigned cflip = ((unsigned)(q + 1) << 30) & 0x80000000u;    // (q + 1) & 2
-    s = __hiloint2double(__double2hiint(s0) ^ (int)sflip, __double2loint(s0));
-    c = __hiloint2double(__double2hiint(c0) ^ (int)cflip, __double2loint(c0));
+    constexpr double kMagic = 6755399441055744.0;   // 1.5 * 2^52
+    const double t = fma(x, 3.18309886183790691216e-01, kMagic);
+    const double fk = t - kMagic;
+    double r = fma(-fk, 2.0 * 1.57079632673412561417e+00, x);
+    r = fma(-fk, 2.0 * 6.07710050630396597660e-11, r);
+    r = fma(-fk, 2.0 * 2.02226624879595063154e-21, r);
+    const double w = r * r;
+    double ps = fma(w, 1.58969099521155010221e-10 / 4096.0, -2.50507602534068634195e-08 / 1024.0);
+    double pc = fma(w, -1.13596475577881948265e-11 / 16384.0, 2.08757232129817482790e-09 / 4096.0);
+    ps = fma(w, ps, 2.75573137070700676789e-06 / 256.0);
+    pc = fma(w, pc, -2.75573143513906633035e-07 / 1024.0);
+    ps = fma(w, ps, -1.98412698298579493134e-04 / 64.0);
+    pc = fma(w, pc, 2.48015872894767294178e-05 / 256.0);
+    ps = fma(w, ps, 8.33333333332248946124e-03 / 16.0);
+    pc = fma(w, pc, -1.38888888888741095749e-03 / 64.0);
+    ps = fma(w, ps, -1.66666666666666324348e-01 / 4.0);
+    pc = fma(w, pc, 4.16666666666666019037e-02 / 16.0);
+    const double sh2 = fma(r * w, ps, r);                       // 2 sin(r / 2)
+    const double ch = fma(w * w, pc, fma(-0.125, w, 1.0));      // cos(r / 2)
+    const double sa = sh2 * ch;
+    const double ca = fma(sh2 * sh2, -0.5, 1.0);
+    const int flip = (int)((unsigned)__double2loint(t) << 31);  // k odd: both change sign
+    s = __hiloint2double(__double2hiint(sa) ^ flip, __double2loint(sa));
+    c = __hiloint2double(__double2hiint(ca) ^ flip, __double2loint(ca));
 }
 template <int K> __device__ __forceinline__ void sincos_g(const Dual<K>& x, Dual<K>& s, Dual<K>& c) {
     double sv, cv;
@@ -401,10 +402,11 @@ __device__ __forceinline__ void env_dynamics(const trajopt_env_t& e, const X (&x
 // The clip of a double as exactly two instructions.  fmin(fmax(x, -lim), lim) makes hipcc quiet its operands first (a
 // v_max_f64 x, x per limit - and it prefers recomputing those in the time loop to holding them: ten instructions a
 // cartpole step); the hardware instructions already implement minnum / maxnum on any input (IEEE mode quiets a
-// signalling NaN by itself), so the results are the same bit for bit.  nlim = -lim, prepared by the caller.
-__device__ __forceinline__ double clip_hw(double x, double nlim, double lim) {
+// signalling NaN by itself), so the results are the same bit for bit.  The lower limit is the upper one under the
+// instruction's negate modifier: no register (or, as hipcc kept it, high word + a move per use) for -lim.
+__device__ __forceinline__ double clip_hw(double x, double lim) {
     double r;
-    asm("v_max_f64 %0, %1, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(r) : "v"(x), "v"(nlim), "v"(lim));
+    asm("v_max_f64 %0, %1, -%2\n\tv_min_f64 %0, %0, %2" : "=&v"(r) : "v"(x), "v"(lim));
     return r;
 }
 __device__ __forceinline__ double max_hw(double a, double b) {
@@ -413,11 +415,10 @@ __device__ __forceinline__ double max_hw(double a, double b) {
     return r;
 }
 
-// env_dynamics<MODEL, double, false> with the state clip as clip_hw (the rollout's time loop); nxmax = -e.xmax.
+// env_dynamics<MODEL, double, false> with the state clip as clip_hw (the rollout's time loop).
 template <int MODEL>
 __device__ __forceinline__ void env_dynamics_hw(const trajopt_env_t& e, const double (&x)[Model<MODEL>::N],
-                                                const double (&u)[Model<MODEL>::M], double (&xn)[Model<MODEL>::N],
-                                                const double (&nxmax)[Model<MODEL>::N]) {
+                                                const double (&u)[Model<MODEL>::M], double (&xn)[Model<MODEL>::N]) {
     constexpr int N = Model<MODEL>::N;
     const double dt = ReverseTime<MODEL>::value ? -e.dt : e.dt;
     double k1[N], k2[N], k3[N], k4[N], y[N];
@@ -434,7 +435,7 @@ __device__ __forceinline__ void env_dynamics_hw(const trajopt_env_t& e, const do
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const double s = x[i] + (dt / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
-        xn[i] = clip_hw(s, nxmax[i], e.xmax[i]);
+        xn[i] = clip_hw(s, e.xmax[i]);
     }
 }
 

@@ -72,9 +72,14 @@ constexpr int kStagePad = 10;
 #define ROLL_DIAG 0   // timing experiments only (wrong results): 1 = no write-out of the staged blocks, 2 = no staging either
 #endif
 typedef double stage_v2 __attribute__((ext_vector_type(2)));
-template <int ROWS>
+// Models with more than 8 rows a step (quadrotor: 16) stage HALF blocks: 4 steps x 64 lanes per element, unpadded (32 KB
+// a wave at 16 rows, where whole padded blocks would take 82 KB - one wave per CU), written out as 32-byte half cells,
+// which are whole sectors.  Round 2 wrote those models' candidates straight from the lanes instead, 8 bytes a lane and 64
+// cells a store: the 16 stores of a step were 70 % of the quadrotor's rollout (3.27 ms with them, 1.00 ms without).
+constexpr int kHalfSteps = 4;
+template <int ROWS, int PAD = kStagePad>
 struct alignas(16) TbStage {
-    double v[ROWS * 64 * kStagePad];
+    double v[ROWS * 64 * PAD];
     unsigned long long bx[64], bu[64];   // per lane-problem: element offset of (block 0, row 0) in state / action
 };
 // rows [row0, row0 + rows) of the stage = block `blk` of `base` (a plane set with `rows` rows per block)
@@ -101,6 +106,28 @@ __device__ __forceinline__ void tb_flush(const TbStage<ROWS>& sg, const unsigned
     __builtin_amdgcn_wave_barrier();
 }
 
+// Half blocks (TbStage<ROWS, kHalfSteps>): rows [row0, row0 + rows) of the stage = steps 4 hb .. 4 hb + 3 of `base`.  A store
+// covers 32 lane-problems with their 4 steps each (16 bytes a lane, two lanes a half cell).
+template <int ROWS>
+__device__ __forceinline__ void tb_flush_half(const TbStage<ROWS, kHalfSteps>& sg, const unsigned long long* off, double* base,
+                                              int row0, int rows, int hb, size_t NP, unsigned lane) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned sp = lane & 1u, pj = lane >> 1;
+    const size_t rstride = NP * kTB;
+    double* dst0 = base + ((size_t)(hb >> 1) * rows) * rstride + (size_t)(hb & 1) * kHalfSteps + 2 * sp;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const unsigned prob = (unsigned)k * 32 + pj;
+        double* d = dst0 + off[prob];
+        for (int r = 0; r < rows; ++r)
+            *reinterpret_cast<stage_v2*>(d + (size_t)r * rstride) =
+                *reinterpret_cast<const stage_v2*>(&sg.v[((row0 + r) * 64 + prob) * kHalfSteps + 2 * sp]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // MINOR: layout of x0 / xref / uref / candidates;  KMINOR: layout of the gains K, kff (the batched driver keeps
 // them PROBLEM_MAJOR for the matrix-core backward kernel when dx > 6).
 // FAST: the batched driver's call - state and action planes given, no per-step cost plane, plain cost (no slew rate,
@@ -113,9 +140,19 @@ __device__ __forceinline__ void tb_flush(const TbStage<ROWS>& sg, const unsigned
 // CO (with FAST, without TB): returns only, no trajectory is written - the first pass of the two-pass line search.
 // (The returns-only cartpole takes 176 registers, 2 waves per SIMD; held to 168 for 3 - __launch_bounds__(64, 3), 36
 // bytes of spills - 65 536 cartpoles took 8.4 instead of 7.8 ms an iteration, 16 384 2.98 instead of 2.76.)
-template <class SYS, bool MINOR, bool KMINOR, bool FAST, bool TB, bool UNR, bool CO = false>
+// KL (with FAST, TB, PROBLEM_MAJOR gains, dx + du > 8, the alphas of a problem in neighbouring lanes, >= 8 alphas): the
+// gains K_t reach the lanes THROUGH LDS.  A wave then holds at most 8 different problems, i.e. 8 different K_t, but
+// lane by lane that was 64 copies of dx du doubles (quadrotor: 96 registers, 48 load instructions a step, and with the
+// dynamics next to them 512 registers were not enough: the set went through AGPRs and ~30 doubles through scratch,
+// each behind a full wait).  Here lane l fetches an eighth of the K_t of the wave's problem l / 8 a step ahead (dx du / 8
+// doubles, 16 bytes a load), the wave writes the 8 matrices into its LDS image at the top of the step and every lane
+// reads its problem's rows from there as the control law consumes them (slots padded by 2 doubles: the 8 rows a wave
+// reads at once fall into different banks).  Same products in the same order: results are bitwise those of KL = false.
+template <class SYS, bool MINOR, bool KMINOR, bool FAST, bool TB, bool UNR, bool CO = false, bool KL = false>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     constexpr int N = SYS::N, M = SYS::M;
+    static_assert(!KL || (FAST && TB && !KMINOR && !UNR && !CO && (M * N) % 16 == 0), "KL: see above");
+    constexpr int kKSlot = M * N + 2;   // doubles per problem in the LDS image of the gains
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned lane = threadIdx.x;
     const size_t NP = a.NP;
@@ -159,12 +196,12 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     // back from LDS lives in VGPRs (plentiful here); only the fields a model uses survive as registers.  The LQR
     // env indexes its matrices with run-time dimensions and keeps the kernel-argument copy.
     __shared__ trajopt_env_t s_env;
-    // Models with more than 8 rows a step (quadrotor: 16) write their candidates straight into the time-blocked planes,
-    // 8 bytes a lane: the stage would take 85 KB a wave (one wave per CU), and with ~2500 fp64 instructions a step the
-    // stores are a small part of such a rollout - the write-combining of L2 / the memory-side cache has 8 steps' time
-    // to complete a 64-byte cell.
-    constexpr bool kDirect = TB && (N + M > 8);
-    __shared__ TbStage<(TB && !kDirect) ? N + M : 1> s_stage;
+    // Models with more than 8 rows a step (quadrotor: 16) stage half blocks (TbStage above)
+    constexpr bool kHalf = TB && (N + M > 8);
+    constexpr int kSteps = kHalf ? kHalfSteps : kTB, kPad = kHalf ? kHalfSteps : kStagePad;
+    __shared__ TbStage<TB ? N + M : 1, kPad> s_stage;
+    typedef double kl_v2 __attribute__((ext_vector_type(2)));
+    __shared__ kl_v2 s_gains[KL ? 8 * kKSlot / 2 : 1];
     if constexpr (SYS::kStatic) {
         // everything but the LQR matrices: [0, lin_A) and [phys, end) - 64 doubles, one pass of the wave
         constexpr unsigned kHead = offsetof(trajopt_env_t, lin_A) / sizeof(double);
@@ -219,7 +256,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     double* ac = (!TB && a.action) ? a.action + plane * Em * NP : nullptr;
     double* co = a.cost ? a.cost + (size_t)ai * (size_t)(T + 1) * NP : nullptr;
     const size_t bx_own = TB ? plane * tb_plane(n, T + 1, NP) + p * kTB : 0, bu_own = TB ? plane * tb_plane(m, T, NP) + p * kTB : 0;
-    if constexpr (TB && !kDirect) {
+    if constexpr (TB) {
         s_stage.bx[lane] = bx_own;
         s_stage.bu[lane] = bu_own;
     }
@@ -228,23 +265,32 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     // 0 of the next block, is put - and whatever the last, partial blocks hold after the last step.
     auto put_x = [&](int s, int i, double v) {
         if (ROLL_DIAG >= 2) return;
-        if constexpr (kDirect) a.state[bx_own + ((size_t)(s / kTB) * n + i) * NP * kTB + (s & (kTB - 1))] = v;
-        else s_stage.v[(i * 64 + lane) * kStagePad + (s & (kTB - 1))] = v;
+        s_stage.v[(i * 64 + lane) * kPad + (s & (kSteps - 1))] = v;
     };
     auto put_u = [&](int t, int j, double v) {
         if (ROLL_DIAG >= 2) return;
-        if constexpr (kDirect) a.action[bu_own + ((size_t)(t / kTB) * m + j) * NP * kTB + (t & (kTB - 1))] = v;
-        else s_stage.v[((n + j) * 64 + lane) * kStagePad + (t & (kTB - 1))] = v;
+        s_stage.v[((n + j) * 64 + lane) * kPad + (t & (kSteps - 1))] = v;
     };
+    // b: the block (of kSteps steps: 8, or 4 for the half-block stage) that is complete
     auto flush_block = [&](int b) {
-        if (ROLL_DIAG >= 1 || kDirect) return;
-        tb_flush(s_stage, s_stage.bx, a.state, 0, n, b, NP, lane);
-        tb_flush(s_stage, s_stage.bu, a.action, n, m, b, NP, lane);
+        if (ROLL_DIAG >= 1) return;
+        if constexpr (kHalf) {
+            tb_flush_half(s_stage, s_stage.bx, a.state, 0, n, b, NP, lane);
+            tb_flush_half(s_stage, s_stage.bu, a.action, n, m, b, NP, lane);
+        } else if constexpr (TB) {
+            tb_flush(s_stage, s_stage.bx, a.state, 0, n, b, NP, lane);
+            tb_flush(s_stage, s_stage.bu, a.action, n, m, b, NP, lane);
+        }
     };
-    auto flush_tail = [&]() {   // slices 8 (T / 8) .. T of the states, .. T - 1 of the actions
-        if (kDirect) return;
-        tb_flush(s_stage, s_stage.bx, a.state, 0, n, T / kTB, NP, lane);
-        if (T % kTB != 0) tb_flush(s_stage, s_stage.bu, a.action, n, m, T / kTB, NP, lane);
+    auto flush_tail = [&]() {   // slices kSteps (T / kSteps) .. T of the states, .. T - 1 of the actions
+        if (ROLL_DIAG >= 1) return;
+        if constexpr (kHalf) {
+            tb_flush_half(s_stage, s_stage.bx, a.state, 0, n, T / kSteps, NP, lane);
+            if (T % kSteps != 0) tb_flush_half(s_stage, s_stage.bu, a.action, n, m, T / kSteps, NP, lane);
+        } else if constexpr (TB) {
+            tb_flush(s_stage, s_stage.bx, a.state, 0, n, T / kTB, NP, lane);
+            if (T % kTB != 0) tb_flush(s_stage, s_stage.bu, a.action, n, m, T / kTB, NP, lane);
+        }
     };
 
     double x[N], xr[N], ur[M], kf[M], Kt[M * N];
@@ -264,7 +310,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         // step t as soon as its control law has consumed them (two named sets; unconditionally: the last slice is simply
         // loaded again) - the generic loop below costs ~65 address / copy instructions per step, a sixth of the step.
         static_assert(MINOR && SYS::kStatic, "FAST is instantiated for the struct-of-arrays layout and static dimensions only");
-        struct In { double xr[N], ur[M], kf[M], K[M * N], w; };
+        constexpr int kKq = KL ? M * N / 16 : 1;   // KL: 16-byte pieces of K_t a lane fetches for the wave
+        struct In { double xr[N], ur[M], kf[M], K[KL ? 1 : M * N], w; kl_v2 kq[kKq]; };
         // Every load is  buffer_load_dwordx2 v, v_lane, s[descriptor of the array's current slice], s_element offen :
         // the descriptor's base is the wave-uniform slice pointer (advanced with two scalar adds a step), the element's
         // offset a loop-invariant SGPR and the lane's offset ONE VGPR per array - as a flat load every element cost a
@@ -281,11 +328,18 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         auto bl = [](__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) {
             return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, v, so, 0));
         };
-        double numax[M], nxmax[N], xtop = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < M; ++j) numax[j] = -e.umax[j];
-#pragma unroll
-        for (int i = 0; i < N; ++i) nxmax[i] = -e.xmax[i];
+        double xtop = -INFINITY;
+        // KL: the wave's idx range covers the problems p_lo .. p_lo + 7 at most (launch_rollout checks nA >= 8); lane l
+        // fetches piece l % 8 of problem p_lo + l / 8 (clamped: a fetch without a reader), and reads slot p - p_lo
+        unsigned vKq = 0, lds_put = 0, lds_get = 0;
+        if constexpr (KL) {
+            const size_t nA = (size_t)(a.nb_alphas - a.alpha_begin);
+            const size_t p_lo = ((size_t)blockIdx.x * 64) / nA;
+            const size_t pd = p_lo + lane / 8 < NP ? p_lo + lane / 8 : NP - 1;
+            vKq = (unsigned)((((size_t)gains_bank(a.out_bank, pd) * NP + pd) * Enm) * 8) + (lane % 8) * (unsigned)(M * N);
+            lds_put = (lane / 8) * (unsigned)(kKSlot / 2) + (lane % 8) * (unsigned)kKq;
+            lds_get = (idle || p < p_lo || p - p_lo > 7 ? 0u : (unsigned)(p - p_lo)) * (unsigned)(kKSlot / 2);
+        }
         int tl = 0;  // the slice the pointers address
         auto load = [&](In& s) {
             const __amdgpu_buffer_rsrc_t rx = rs(pxr), ru = rs(pur), rk = rs(pK), rf = rs(pkf);
@@ -296,8 +350,14 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 s.ur[j] = bl(ru, p8, (unsigned)j * np8);
                 s.kf[j] = KMINOR ? bl(rf, vkf, (unsigned)j * np8) : bl(rf, vkf + 8u * j, 0u);
             }
+            if constexpr (KL) {
 #pragma unroll
-            for (int k = 0; k < M * N; ++k) s.K[k] = KMINOR ? bl(rk, vK, (unsigned)k * np8) : bl(rk, vK + 8u * k, 0u);
+                for (int k = 0; k < kKq; ++k)
+                    s.kq[k] = __builtin_bit_cast(kl_v2, __builtin_amdgcn_raw_buffer_load_b128(rk, vKq + 16u * k, 0u, 0));
+            } else {
+#pragma unroll
+                for (int k = 0; k < M * N; ++k) s.K[k] = KMINOR ? bl(rk, vK, (unsigned)k * np8) : bl(rk, vK + 8u * k, 0u);
+            }
             s.w = *reinterpret_cast<const double*>(pw);
             if (tl + 1 < T) { pxr += sx; pur += su; pK += sK; pkf += skf; pw += 8; ++tl; }
         };
@@ -319,20 +379,45 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         // seen to have arrived once those 40 stores have been acknowledged.
         // (kAhead2: for the lone-wave forms.  Where several waves share a SIMD they hide that wait for each other, and
         // the plain one-step-ahead prefetch into the other register set needs fewer registers - an occupancy step for dx = 6.)
-        constexpr bool kAhead2 = (!TB || UNR) && !CO;
+        constexpr bool kAhead2 = (!TB || (UNR && !kHalf)) && !CO;
         // (kOne: models with more than 8 rows a step - two register sets of their inputs (quadrotor: 68 doubles each)
         // do not fit next to the dynamics; ONE set, refilled in place with the next step's inputs as soon as the control
         // law has consumed it - they arrive while the dynamics integrate.)
-        constexpr bool kOne = kDirect && !kAhead2;
+        constexpr bool kOne = kHalf;
         auto step = [&](In& s, auto put_next_c) {
             constexpr bool put_next = decltype(put_next_c)::value;
             double u[M];  // u = clip(uref + alpha kff + K (x - xref))    objects.py:137-139, ilqr.py:97
+            if constexpr (KL) {
+                // the wave's LDS queue is in order: these writes follow the previous step's reads, the reads below follow them
 #pragma unroll
-            for (int j = 0; j < M; ++j) {
-                double kx = 0.0;
+                for (int k = 0; k < kKq; ++k) s_gains[lds_put + k] = s.kq[k];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                double kx[M];
 #pragma unroll
-                for (int i = 0; i < N; ++i) kx = fma(s.K[j + M * i], x[i] - s.xr[i], kx);
-                u[j] = clip_hw(fma(alpha, s.kf[j], s.ur[j]) + kx, numax[j], e.umax[j]);
+                for (int j = 0; j < M; ++j) kx[j] = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double dxi = x[i] - s.xr[i];
+#pragma unroll
+                    for (int j = 0; j < M; j += 2) {
+                        const kl_v2 kk = s_gains[lds_get + (M * i + j) / 2];
+                        kx[j] = fma(kk.x, dxi, kx[j]);
+                        if (j + 1 < M) kx[j + 1] = fma(kk.y, dxi, kx[j + 1]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < M; ++j) u[j] = clip_hw(fma(alpha, s.kf[j], s.ur[j]) + kx[j], e.umax[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    double kx = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) kx = fma(s.K[j + M * i], x[i] - s.xr[i], kx);
+                    u[j] = clip_hw(fma(alpha, s.kf[j], s.ur[j]) + kx, e.umax[j]);
+                }
             }
             total += env_cost_plain<N, M>(e, x, u, s.w);  // ilqr.py:98 passes u_last = u_t
             if constexpr (kAhead2 || kOne) load(s);
@@ -342,7 +427,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
                 else if constexpr (!CO) { *ap[j] = u[j]; ap[j] += dsu; }
             }
             double xn[N];
-            SYS::dynamics_clipped_hw(e, x, u, xn, nxmax);
+            SYS::dynamics_clipped_hw(e, x, u, xn);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 x[i] = xn[i];
@@ -361,9 +446,19 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
             // no stores on the first it would make every block wait for ALL but the newest loads, i.e. for its own
             // write-out to be acknowledged.
             flush_block(0);
-            const int nblk = T / kTB;
+            const int nblk = T / kSteps;
             for (int b = 0; b < nblk; ++b) {
-                if constexpr (UNR) {
+                if constexpr (kHalf) {
+                    // one register set, four straight-line steps: a single loop whose only entries are the dummy write-out
+                    // above and its own back edge, both with a half block's stores behind the loads of the next inputs
+#pragma unroll
+                    for (int k = 0; k < kHalfSteps - 1; ++k) {
+                        step(sa, std::true_type{});
+                        ++t;
+                    }
+                    step(sa, std::false_type{});
+                    ++t;
+                } else if constexpr (UNR) {
 #pragma unroll
                     for (int k = 0; k < kTB / 2; ++k) {
                         if constexpr (!kAhead2 && !kOne) load(sb);
@@ -395,7 +490,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) put_x(t, i, x[i]);   // slice 8 b + 8 = slot 0 of the next block
             }
-            while (t < T) {   // the last, partial block: fewer than 8 steps
+            while (t < T) {   // the last, partial block: fewer than 8 (4) steps
                 if constexpr (!kAhead2 && !kOne) load(sb);
                 step(sa, std::true_type{});
                 if (++t >= T) break;
@@ -472,7 +567,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         double xn[N];
         SYS::dynamics_clipped(e, x, u, xn);  // u is clipped above
         if constexpr (TB) {
-            if ((t & (kTB - 1)) == kTB - 1) flush_block(t / kTB);
+            if ((t & (kSteps - 1)) == kSteps - 1) flush_block(t / kSteps);
         }
 #pragma unroll
         for (int i = 0; i < N; ++i)
@@ -534,6 +629,15 @@ bool rollout_straight_line(int n, int m, size_t NP, int nb_alphas) {
     return (double)NP * nb_alphas <= 64.0 * 1024.0 && n + m <= 7;
 }
 
+// KL form of the driver's rollout (gains through LDS): see rollout_kernel.  alpha_minor implies PROBLEM_MAJOR gains,
+// no problem list and no second pass; with >= 8 alphas 64 consecutive (problem, alpha) pairs hold <= 8 problems.
+#ifndef ROLL_NO_KL
+#define ROLL_NO_KL 0
+#endif
+bool rollout_gains_through_lds(int n, int m, int alpha_minor, int nb_alphas) {
+    return !ROLL_NO_KL && alpha_minor && nb_alphas >= 8 && n + m > 8 && (n * m) % 16 == 0;
+}
+
 // The returns-only form (CO) exists for the variant the driver's plain-cost call takes (FAST in rollout_kernel).
 bool rollout_cost_only_supported(const trajopt_env_t* env, int T, int64_t NP, int k_layout) {
     if (env->model == TRAJOPT_ENV_LQR || env->slew_rate || env->periodic != 0 || env->cost_times_dt || env->nb_features != 0 || T <= 0)
@@ -576,6 +680,10 @@ struct RolloutLaunch {
                 if (tb && unr && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, true, true>), grid, block, 0, st, a);
                 else if (tb && unr) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, true, true>), grid, block, 0, st, a);
                 else if (tb && kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, true, false>), grid, block, 0, st, a);
+                else if (tb && rollout_gains_through_lds(SYS::N, SYS::M, a.alpha_minor, (int)nA)) {
+                    if constexpr (SYS::N + SYS::M > 8 && (SYS::N * SYS::M) % 16 == 0)
+                        hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, true, false, false, true>), grid, block, 0, st, a);
+                }
                 else if (tb) hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, true, false>), grid, block, 0, st, a);
                 else if (kmi) hipLaunchKernelGGL((rollout_kernel<SYS, true, true, true, false, false>), grid, block, 0, st, a);
                 else hipLaunchKernelGGL((rollout_kernel<SYS, true, false, true, false, false>), grid, block, 0, st, a);

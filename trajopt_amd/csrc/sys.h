@@ -20,10 +20,10 @@ struct SysPhys {
                                                             const double (&u)[M], double (&xn)[N]) {
         env_dynamics<MODEL, double, false>(e, x, u, xn);
     }
-    // ... and the state clip as two hardware instructions per state (env_models.h: clip_hw); nxmax = -e.xmax
+    // ... and the state clip as two hardware instructions per state (env_models.h: clip_hw)
     static __device__ __forceinline__ void dynamics_clipped_hw(const trajopt_env_t& e, const double (&x)[N],
-                                                               const double (&u)[M], double (&xn)[N], const double (&nxmax)[N]) {
-        env_dynamics_hw<MODEL>(e, x, u, xn, nxmax);
+                                                               const double (&u)[M], double (&xn)[N]) {
+        env_dynamics_hw<MODEL>(e, x, u, xn);
     }
     // Columns [k0, k0+KC) of the Jacobian [A | B] of env.dynamics at (x, u): J[i][k - k0].
     template <int KC>
