@@ -196,8 +196,16 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     // back from LDS lives in VGPRs (plentiful here); only the fields a model uses survive as registers.  The LQR
     // env indexes its matrices with run-time dimensions and keeps the kernel-argument copy.
     __shared__ trajopt_env_t s_env;
-    // Models with more than 8 rows a step (quadrotor: 16) stage half blocks (TbStage above)
-    constexpr bool kHalf = TB && (N + M > 8);
+    // Models with more than 8 rows a step (quadrotor: 16) stage half blocks (TbStage above).
+    // (ROLL_HALF_SMALL = 1 gives the rolled forms of the small models the half-block stage too - double cartpole: 17 KB
+    // instead of 39 KB of LDS and 232 registers, i.e. two waves per SIMD, so that the 1408 waves of 8192 x 11 alphas are
+    // resident at once instead of going through the chip in two rounds.  Measured, A/B on one box: slower everywhere -
+    // 8192 double cartpoles 1.55 -> 2.02 ms, 16 384: 2.6 -> 3.2, 7168 cartpoles 0.88 -> 1.12, 131 072 cartpoles 8.9 ->
+    // 9.4: two waves of a vector-bound chain share one pipe, and the write-out is twice as many, half as wide stores.)
+#ifndef ROLL_HALF_SMALL
+#define ROLL_HALF_SMALL 0
+#endif
+    constexpr bool kHalf = TB && (N + M > 8 || (ROLL_HALF_SMALL && !UNR));
     constexpr int kSteps = kHalf ? kHalfSteps : kTB, kPad = kHalf ? kHalfSteps : kStagePad;
     __shared__ TbStage<TB ? N + M : 1, kPad> s_stage;
     typedef double kl_v2 __attribute__((ext_vector_type(2)));
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         // (kOne: models with more than 8 rows a step - two register sets of their inputs (quadrotor: 68 doubles each)
         // do not fit next to the dynamics; ONE set, refilled in place with the next step's inputs as soon as the control
         // law has consumed it - they arrive while the dynamics integrate.)
-        constexpr bool kOne = kHalf;
+        constexpr bool kOne = TB && (N + M > 8);
         auto step = [&](In& s, auto put_next_c) {
             constexpr bool put_next = decltype(put_next_c)::value;
             double u[M];  // u = clip(uref + alpha kff + K (x - xref))    objects.py:137-139, ilqr.py:97
@@ -449,15 +457,18 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
             const int nblk = T / kSteps;
             for (int b = 0; b < nblk; ++b) {
                 if constexpr (kHalf) {
-                    // one register set, four straight-line steps: a single loop whose only entries are the dummy write-out
-                    // above and its own back edge, both with a half block's stores behind the loads of the next inputs
+                    // four straight-line steps: a single loop whose only entries are the dummy write-out above and its
+                    // own back edge, both with a half block's stores behind the loads of the next inputs
 #pragma unroll
-                    for (int k = 0; k < kHalfSteps - 1; ++k) {
+                    for (int k = 0; k < kHalfSteps / 2; ++k) {
+                        if constexpr (!kAhead2 && !kOne) load(sb);
                         step(sa, std::true_type{});
                         ++t;
+                        if constexpr (!kAhead2 && !kOne) load(sa);
+                        if (k + 1 < kHalfSteps / 2) step(kOne ? sa : sb, std::true_type{});
+                        else step(kOne ? sa : sb, std::false_type{});
+                        ++t;
                     }
-                    step(sa, std::false_type{});
-                    ++t;
                 } else if constexpr (UNR) {
 #pragma unroll
                     for (int k = 0; k < kTB / 2; ++k) {
