@@ -429,6 +429,8 @@ def main():
     ap.add_argument("--alphas", type=int, default=11, help="the first k of the reference's 11 step sizes (C4: 8)")
     ap.add_argument("--staged", type=int, default=-1, help="line search: -1 auto, 0 one launch, 1 staged, 2 returns first then the accepted alpha again (same results)")
     ap.add_argument("--no-fusion", action="store_true", help="quadratise and backward pass as two launches (same results)")
+    ap.add_argument("--max-lmbda", type=float, default=float("inf"),
+                    help="headline line only: the reference's give-up rule (ilqr.py:17 uses 1e6); inf = every problem iterates in every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="the headline line only")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -479,7 +481,7 @@ def main():
     N, T, K, W = a.instances, a.horizon, a.steps, a.warmup
     alphas = ALL_ALPHAS[:a.alphas]
     cx = Ctx(torch, _lib.lib(), dist, red_dev, rank, world)
-    r = iteration_line(cx, a.env, N, T, alphas, K, W, 1337 + rank, staged=a.staged, no_fusion=a.no_fusion)
+    r = iteration_line(cx, a.env, N, T, alphas, K, W, 1337 + rank, staged=a.staged, no_fusion=a.no_fusion, max_lmbda=a.max_lmbda)
     stamp = _lib.source_stamp()
     n, m = r["n"], r["m"]
 
