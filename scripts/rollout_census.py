@@ -44,7 +44,8 @@ def main():
             subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "isa_census.py"), asm, key, js])
             loops = json.load(open(js))["loops"]
             # the largest loop closed by a conditional branch = the block loop (8 straight-line steps)
-            big = max((l for l in loops if l["conditional"]), key=lambda l: l["instructions"])
+            # (the half-block form's 4-step loop closes with an unconditional branch; its tail loop of single steps is smaller)
+            big = max((l for l in loops if l["conditional"] or env in STEPS_PER_TRIP), key=lambda l: l["instructions"])
             spt = float(STEPS_PER_TRIP.get(env, 8))
             per_step = {k: v / spt for k, v in big["by_category"].items()}
             res["kernels"][env] = {"mangled": key, "trip_instructions": big["instructions"], "steps_per_trip": spt,

@@ -1,3 +1,7 @@
+// CPU restatement of the device sin / cos of trajopt_amd/csrc/env_models.h (sincos_g), the same operations in the same
+// order with fma(), checked against long double libm on random arguments per decade and near multiples of pi / 4.
+//   gcc -O2 -ffp-contract=off sincos_check.c -o sincos_check -lm && ./sincos_check [samples per decade]
+// `old` is the form it replaced (reduction by pi / 2 without its big-argument guard), for comparison.
 #include <math.h>
 #include <stdio.h>
 #include <stdint.h>
@@ -55,12 +59,13 @@ static void sc_new(double x,double*s,double*c){
     const uint64_t sg = (uint64_t)((uint32_t)d2u(t) << 31) << 32;
     *s = u2d(d2u(sa) ^ sg); *c = u2d(d2u(ca) ^ sg);
 }
-int main(){
+int main(int argc, char** argv){
+    const int NS = argc > 1 ? atoi(argv[1]) : 2000000;
     double mo_s=0,mo_c=0,mn_s=0,mn_c=0; srand48(1);
     double scales[] = {1, 10, 1000, 1e5, 1e6, 1e9, 1e12, 1e15};
     for (int k=0;k<8;k++){
       mo_s=mo_c=mn_s=mn_c=0;
-      for (int i=0;i<2000000;i++){
+      for (int i=0;i<NS;i++){
         double x = (drand48()*2-1)*scales[k];
         if (i<1000) x = (i-500)*M_PI/4 * (1+ (drand48()-0.5)*1e-12) * (k<3?1:scales[k]/1000);   // near multiples of pi/4
         long double sl=sinl((long double)x), cl=cosl((long double)x);

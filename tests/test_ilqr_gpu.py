@@ -81,6 +81,43 @@ def test_env_step_matches_oracle(oracle, name, layout):
         assert abs(cost[p] - c) <= 1e-12 * max(abs(c), 1e-300), (name, p, cost[p], c)
 
 
+@pytest.mark.parametrize("name", ["pendulum", "cartpole", "double_cartpole", "double_pendulum"])
+def test_env_step_at_large_angles(oracle, name):
+    """The device sin / cos has no big-argument path (env_models.h: reduction by pi with one FMA per Cody-Waite term, valid
+    to |x| ~ 2^51): angles of 1e2 .. 1e12 rad must give the oracle's (libm's) step.  The comparison itself is conditioned
+    by the angle's own ulp - a fused and an unfused `x + h k` differ by one ulp of x, and sin moves by as much - so the bar
+    is 1e-12 + 64 ulp(|angle|); a reduction that loses the argument (what dropping a Payne-Hanek path naively would do)
+    is off by O(1)."""
+    import torch
+    from trajopt_amd import _lib
+    pe, oe = _pair(name)
+    rng = np.random.default_rng(11)
+    N = 260
+    n, m = pe.dm_state, pe.dm_act
+    x = _rand_state(name, rng, N)
+    ang = {"pendulum": [0], "cartpole": [1], "double_cartpole": [1, 2], "double_pendulum": [0, 1]}[name]
+    mag = 10.0 ** rng.uniform(2.0, 12.0, (N, len(ang))) * rng.choice([-1.0, 1.0], (N, len(ang)))
+    x[:, ang] = mag
+    u = rng.standard_normal((N, m))
+    e = pe.struct()
+    dx, du = (torch.as_tensor(np.ascontiguousarray(v), device="cuda") for v in (x, u))
+    da = torch.ones(N, dtype=torch.float64, device="cuda")
+    xn = torch.empty_like(dx)
+    cost = torch.empty(N, dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib().trajopt_env_step_batched(C.byref(e), _lib.dptr(dx), _lib.dptr(du), _lib.dptr(du), _lib.dptr(da),
+                                                   C.c_int64(N), 0, _lib.dptr(xn), _lib.dptr(cost), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    xn = xn.cpu().numpy()
+    assert np.all(np.isfinite(xn))
+    worst = 0.0
+    for p in range(N):
+        ref = oracle.env_dynamics(oe, x[p], u[p])
+        tol = 1e-12 + 64.0 * np.spacing(np.max(np.abs(mag[p])))
+        err = np.max(np.abs(xn[p] - ref) / np.maximum(np.abs(ref), 1.0))
+        worst = max(worst, err / tol)
+        assert err <= tol, (name, p, mag[p], err, tol)
+
+
 def _rollout_inputs(name, rng, N, T, n, m):
     xref = _rand_state(name, rng, N)[:, :, None] + 0.1 * rng.standard_normal((N, n, T + 1))
     uref = rng.standard_normal((N, m, T))

@@ -84,7 +84,7 @@ template <int K> __device__ __forceinline__ Dual<K> operator/(const Dual<K>& a, 
 //    parity is bit 0 of the low word), r = x - k pi with a three-term Cody-Waite constant.  Each term is one FMA, and
 //    the FMA is what lifts fdlibm's |x| < 2^20 pi/2 limit: k * pi_1 (33-bit constant) need not be representable, only
 //    x - k pi_1 must be, and it is (it spans 2^-32 .. 2^21 for |k| < 2^51).  Measured against long double on 2 M random
-//    arguments per decade: absolute error <= 4.3e-16 up to |x| = 1e12, 6e-16 at 1e15 (scripts/debug/sincos_check.c);
+//    arguments per decade: absolute error <= 4.3e-16 up to |x| = 1e12, 6e-16 at 1e15 (tests/aux/sincos_check.c);
 //    beyond 2^51 pi the result is meaningless (finite garbage, then inf / NaN), as it is for inf / NaN arguments - such
 //    a candidate has left every state bound long before and its return loses the line search either way
 //    (ilqr.py:196 compares false on NaN, init_select_kernel refuses a non-finite return);
