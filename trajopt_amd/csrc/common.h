@@ -31,10 +31,12 @@ constexpr int kMaxLambdaRetries = 128;  // lambda grows super-exponentially: 1e-
 // 1 / x to ~1 ulp from the hardware estimate and two Newton steps: ~45 cycles instead of the ~80 of an IEEE
 // division (no scaling / fix-up: x must be a normal, finite, non-zero number - here always a positive pivot).
 __device__ __forceinline__ double rcp_nr(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(r, fma(-x, r, 1.0), r);
-    r = fma(r, fma(-x, r, 1.0), r);
-    return r;
+    // v_rcp_f64 is good to ~2^-23; one CUBIC step, r (1 + e + e^2) with e = 1 - x r, leaves e^3 ~ 2^-69 - the same
+    // <= 1 ulp as two Newton steps in three dependent FMAs instead of four (these kernels are chains of dependent
+    // instructions: the rollout takes four reciprocals a step, every backward pass at least one)
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
 }
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
