@@ -557,9 +557,9 @@ def test_riccati_forward_pass_and_rollout_equal_the_stepwise_loop():
                                        ("cartpole", dict(dt=0.02, uw=[1e-5]), 19), ("pendulum", dict(dt=0.05, uw=[1e-5]), 13)])
 def test_two_pass_line_search_is_bitwise_the_one_launch_line_search_on_every_model(oracle, name, kw, T):
     """the two-pass line search takes the returns from the returns-only rollout and the accepted trajectory
-    from ANOTHER instantiation (time-blocked, straight-line or rolled; for the quadrotor the direct-store form with
-    PROBLEM_MAJOR gains).  Forced (mode 2) on every model, with a horizon that is not a multiple of the 8-step block
-    (the flush of the partial last block in pass 2), every output must equal the one-launch line search bit for bit."""
+    from ANOTHER instantiation (time-blocked, straight-line or rolled; for the quadrotor the half-block stage with
+    PROBLEM_MAJOR gains - through LDS in the one-launch form, per lane in pass 2).  Forced (mode 2) on every model, with a horizon that is not a multiple of the 8-step block
+    (the flush of the partial last block / half block in pass 2), every output must equal the one-launch line search bit for bit."""
     from trajopt_amd.ilqr import BatchedILQR
     pe, oe = _pair(name, **kw)
     N = 300
