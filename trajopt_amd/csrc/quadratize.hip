@@ -89,17 +89,34 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
         double J[N][KC];
         SYS::template jacobian_cols<KC>(e, x, u, k0, J);
         const size_t Enn = (size_t)n * n * T, Enm = (size_t)n * m * T;
+        // PROBLEM_MAJOR outputs with an even, static dx (quadrotor): a column of a step is dx consecutive doubles at a
+        // 16-byte aligned address - written two rows a store (half as many store instructions, each of which touches
+        // 64 different cache lines whatever its width)
+        typedef double q_v2 __attribute__((ext_vector_type(2)));
+        constexpr bool kPair = !OMINOR && SYS::kStatic && N % 2 == 0;
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             const int col = k0 + k;
             if (col < n) {
+                double* dst = a.A + qi<OMINOR>((size_t)n * n * t + (size_t)n * col, Enn, p, NP);
+                if constexpr (kPair) {
 #pragma unroll
-                for (int i = 0; i < N; ++i)
-                    if (i < n) a.A[qi<OMINOR>((size_t)n * n * t + i + (size_t)n * col, Enn, p, NP)] = J[i][k];
+                    for (int i = 0; i < N; i += 2) *reinterpret_cast<q_v2*>(dst + i) = q_v2{J[i][k], J[i + 1][k]};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        if (i < n) a.A[qi<OMINOR>((size_t)n * n * t + i + (size_t)n * col, Enn, p, NP)] = J[i][k];
+                }
             } else if (col < n + m) {
+                double* dst = a.B + qi<OMINOR>((size_t)n * m * t + (size_t)n * (col - n), Enm, p, NP);
+                if constexpr (kPair) {
 #pragma unroll
-                for (int i = 0; i < N; ++i)
-                    if (i < n) a.B[qi<OMINOR>((size_t)n * m * t + i + (size_t)n * (col - n), Enm, p, NP)] = J[i][k];
+                    for (int i = 0; i < N; i += 2) *reinterpret_cast<q_v2*>(dst + i) = q_v2{J[i][k], J[i + 1][k]};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        if (i < n) a.B[qi<OMINOR>((size_t)n * m * t + i + (size_t)n * (col - n), Enm, p, NP)] = J[i][k];
+                }
             }
         }
     }
