@@ -242,6 +242,7 @@ def _solve_pair(oracle, name, N, T, iters, seed=1337, scale=1e-2, gains_layout=N
     ("cartpole_cartesian", 60, 4, dict(dt=0.02, uw=[1e-5])),  # 8f.3: Cartesian cost - dense Cxx, no structured cost
     ("pendulum_cartesian", 80, 4, dict(dt=0.05, uw=[1e-5])),
     ("double_cartpole_cartesian", 40, 3, dict(dt=0.01, uw=[1e-5])),
+    ("quad_pendulum_cartesian", 22, 2, dict(dt=0.01)),       # dx + du = 12 on the GENERAL rollout (cost features): half-block stage, partial last half
     ("cartpole", 40, 4, dict(dt=0.02, uw=[1e-5], gains_layout=0)),          # forced PROBLEM_MAJOR gains group
     ("double_cartpole", 30, 3, dict(dt=0.01, uw=[1e-5], gains_layout=0)),
     ("quadrotor", 30, 2, dict(dt=0.02, gains_layout=1)),                    # forced PROBLEM_MINOR
