@@ -383,6 +383,71 @@ def test_structured_cost_on_the_matrix_core_kernel_matches_dense_oracle(oracle, 
                 assert_close(L.from_device(o[k], layout)[p], r, "%s[p=%d]" % (k, p))
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("n,m,max_lmbda", [(12, 4, 1e6), (12, 4, 300.0), (5, 2, 1e6)])
+def test_lambda_ladder_in_three_launches_matches_the_sequential_loop(oracle, layout, n, m, max_lmbda):
+    """The driver's configuration of the matrix-core kernel (gains only, reg = 1, structured cost, retries on) runs the
+    lambda ladder of ilqr.py:162-173 in three launches: the first rung (and TRAJOPT_LADDER_INKERNEL retries) inside the
+    wave, the rungs beyond probed in parallel, then a resume at the rung the loop would have stopped at (bwd_mfma16.hip).  A negative control cost makes
+    Quu indefinite until lambda exceeds ~|guu|, and lambda starts anywhere between 1e-4 and 1e2: problems that need no
+    retry, a few (found by a probe), more than the probed rungs (resume and go on
+    alone) and - with a low max_lmbda - problems that give up at every stage.  Final lambda / dlambda, the failure
+    flag and index, gains and dV must be those of looping the oracle."""
+    import torch
+    from trajopt_amd import backward, layout as L, synthetic as S
+    from trajopt_amd._lib import LambdaSchedule
+    T, N = 24, 48
+    rng = np.random.default_rng(5 * n + m)
+    stack = S.backward_inputs(n, m, T, N, seed=900 + n)
+    w = np.abs(rng.standard_normal(T + 1)) + 0.1
+    gxx, guu = np.abs(rng.standard_normal(n)) + 0.5, -(60.0 + 40.0 * rng.random(m))
+    Cxx = np.zeros((N, n, n, T + 1)); Cuu = np.zeros((N, m, m, T + 1)); Cxu = np.zeros((N, n, m, T + 1))
+    Cxx[:, np.arange(n), np.arange(n), :] = gxx[None, :, None] * w[None, None, :]
+    Cuu[:, np.arange(m), np.arange(m), :] = guu[None, :, None]
+    stack = dict(stack, Cxx=Cxx, Cuu=Cuu, Cxu=Cxu)
+    d = {k: L.to_device(stack[k], layout) for k in ("cx", "cu", "A", "B")}
+    lam0 = 10.0 ** rng.uniform(-4.0, 2.3, N)
+    lam0[:4] = [1e-4, 1e-3, 150.0, 250.0]
+    lam = torch.tensor(lam0, dtype=torch.float64, device="cuda")
+    dl = torch.ones(N, dtype=torch.float64, device="cuda")
+    sched = LambdaSchedule(1e-6, max_lmbda, 1.6)
+    o = backward.ilqr_backward_pass(None, d["cx"], None, d["cu"], None, d["A"], d["B"], lam, 1, n, m, T, N, layout,
+                                    kernel=2, full=False, retry=True, sched=sched, dlmbda=dl,
+                                    cost=(torch.as_tensor(w, device="cuda"), gxx, guu))
+    torch.cuda.synchronize()
+    div = o["diverge"].cpu().numpy()
+    lam1, dl1 = lam.cpu().numpy(), dl.cpu().numpy()
+    rungs = []
+    for p in range(N):
+        q = S.problem(stack, p)
+        l, dlm, k = float(lam0[p]), 1.0, 0
+        while True:
+            ref, failed = oracle.backward_pass(q["Cxx"], q["cx"], q["Cuu"], q["cu"], q["Cxu"], q["A"], q["B"], l, 1, n, m, T)
+            if not failed:
+                break
+            dlm = max(dlm * 1.6, 1.6)
+            l = max(l * dlm, 1e-6)
+            if l > max_lmbda:
+                break
+            k += 1
+        rungs.append(k if not failed else -1)
+        assert lam1[p] == pytest.approx(l, rel=1e-15), (p, k)
+        assert dl1[p] == pytest.approx(dlm, rel=1e-15), (p, k)
+        assert (div[p] >= 0) == bool(failed), (p, k, div[p])
+        if failed:
+            assert div[p] == ref[10], (p, k, div[p], ref[10])   # the step the last attempted sweep failed at
+        else:
+            assert div[p] == -1
+            assert_close(L.from_device(o["K"], layout)[p], ref[8], "K[p=%d, rung %d]" % (p, k))
+            assert_close(L.from_device(o["kff"], layout)[p], ref[9], "kff[p=%d, rung %d]" % (p, k))
+            assert_close(L.from_device(o["dV"], layout)[p], ref[7], "dV[p=%d, rung %d]" % (p, k))
+    rungs = np.array(rungs)
+    # the batch must exercise every stage of the ladder
+    assert (rungs == 0).any() and ((rungs >= 1) & (rungs <= 2)).any() and (rungs >= 3).any(), rungs
+    if max_lmbda < 1e6:
+        assert (rungs == -1).any(), rungs
+
+
 def test_a_forced_kernel_family_without_the_shape_is_refused():
     """trajopt_backward_io_t::kernel names a family per call (no global state): where that family has no kernel for
     the shape or layout the call fails with TRAJOPT_ERR_UNSUPPORTED instead of silently taking another one."""

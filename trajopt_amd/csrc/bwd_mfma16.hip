@@ -18,6 +18,7 @@
 // LDL' with one refined reciprocal per pivot: fp64 divisions and square roots cost 80-115 cycles each here);
 // the symmetrisation (util.cpp:161) is one transposed LDS round trip.  Inputs of step t-1 are prefetched
 // unconditionally through per-lane pointers while step t computes.
+#include <cstdlib>
 #include "smallmat.h"
 
 namespace trajopt {
@@ -29,6 +30,13 @@ struct Mf16Args {
     trajopt_lambda_schedule_t sched;
     size_t NP;
     int n, m, T, reg, retry;
+    // The lambda ladder in three launches (launch_sm below).  mode 0: the whole retry loop of ilqr.py:162-173 inside the
+    // wave.  mode 1: the same, but a problem that has failed rung `inkernel` and may still grow lambda is left PENDING
+    // (diverge = -2 - t, lmbda / dlmbda = the state of that rung, dV[slot 0] = INT_MAX as an integer).  The PROBE
+    // instantiation (grid.y = j) then runs rung inkernel + 1 + j of every pending problem without storing anything and
+    // records the lowest rung that succeeds (atomicMin on that integer).  mode 2: a pending problem resumes the loop at
+    // that rung - or, if none of the `rungs` probed ones succeeded, at the last of them lambda's bound allows.
+    int mode, inkernel, rungs;
 };
 
 // index of element e of step t of problem p in an array with `eps` elements per step and `slices` steps
@@ -90,8 +98,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 // instantiation takes any reg at run time.
 // SC: structured cost (trajopt_backward_io_t::cost_w): Cxx_t = w[t] diag(gxx), Cuu = diag(guu), Cxu = 0 are formed in
 // registers instead of being read - 1664 of the 3328 bytes a quadrotor step reads.
-template <int S, int M, bool MINOR, bool FULL, bool R1, bool SC>
+template <int S, int M, bool MINOR, bool FULL, bool R1, bool SC, bool PROBE = false>
 __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
+    static_assert(!PROBE || !FULL, "a probe stores nothing");
     __shared__ double sQ[16 * kLdQ];  // Q (later the unsymmetrised V), element (row, col) at row + kLdQ * col
     __shared__ double sq[16];         // [qx; qu], later v
     __shared__ double sR[4 * 16];     // reg == 2 only: rows n.. of lam * F'F, element (i, col) at i + 4 * col
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
     const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
     const bool live = c < n;
-    const bool want_gn = io.uref != nullptr && io.g_norm != nullptr;
+    const bool want_gn = !PROBE && io.uref != nullptr && io.g_norm != nullptr;
     const int reg = R1 ? 1 : a.reg;
     // structured cost: this lane's entries of the (diagonal) tile C = diag(w gxx, guu) in D layout, rows g + 4 r
     double scx[4], scu[4];
@@ -127,6 +136,33 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
     double dlam = (a.retry && io.dlmbda) ? io.dlmbda[p] : 1.0;
     int div = -1, retries = 0;
     double dV0 = 0.0, dV1 = 0.0, gmax = -INFINITY;
+    bool pending = false;
+    int* const ladder_slot = reinterpret_cast<int*>(&io.dV[MINOR ? p : 2 * p]);   // (little endian: the low word of dV0)
+    auto grow = [&](double& l, double& dl) {   // ilqr.py:166-167; false: lambda has left its bounds, the rung is not run
+        dl = fmax(dl * a.sched.mult_lmbda, a.sched.mult_lmbda);
+        l = fmax(l * dl, a.sched.min_lmbda);
+        return (l <= a.sched.max_lmbda) && (l < 1e300);
+    };
+    if constexpr (PROBE) {
+        if (io.diverge[p] > -2) return;   // not pending
+        for (int i = 0; i <= (int)blockIdx.y; ++i)
+            if (!grow(lam, dlam)) return;
+    } else if (a.mode == 2) {
+        if (io.diverge[p] > -2) return;
+        const int first_ok = *ladder_slot;
+        int adv = 0;
+        if (first_ok != 0x7fffffff) {
+            adv = first_ok + 1;
+        } else {
+            double l = lam, dl = dlam;
+            for (int i = 1; i <= a.rungs; ++i) {
+                if (!grow(l, dl)) break;
+                adv = i;
+            }
+        }
+        for (int i = 0; i < adv; ++i) grow(lam, dlam);
+        retries = a.inkernel + adv;
+    }
 
     for (;;) {
         div = -1;
@@ -329,8 +365,10 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
             Wd = __builtin_amdgcn_mfma_f64_16x16x4f64(Qg, Kg, Wd, 0, 0, 0);
 
             // gains out
-            if (live && g < M) io.K[at_gain<MINOR>(nm, T, t, g + (size_t)m * c, p, NP, kmul, bank)] = Kg;
-            if (c == 0 && g < M) io.kff[at_gain<MINOR>(m, T, t, g, p, NP, kmul, bank)] = kfg;
+            if constexpr (!PROBE) {
+                if (live && g < M) io.K[at_gain<MINOR>(nm, T, t, g + (size_t)m * c, p, NP, kmul, bank)] = Kg;
+                if (c == 0 && g < M) io.kff[at_gain<MINOR>(m, T, t, g, p, NP, kmul, bank)] = kfg;
+            }
             if (want_gn && g == 0 && c < m) gmax = nanmax(gmax, fabs(pick<M>(kf, c)) / (fabs(ur) + 1.0));
 
             wave_lds_fence();  // gains have read sQ / sq
@@ -356,13 +394,30 @@ __global__ __launch_bounds__(64) void bwd_mfma16_kernel(Mf16Args a) {
             Cd = Cn;
             qc = qn;
         }
-        if (div < 0 || !a.retry) break;
+        if (div < 0 || !a.retry || PROBE) break;
+        if (a.mode == 1 && retries >= a.inkernel && retries + 1 < kMaxLambdaRetries) {
+            double l = lam, dl = dlam;
+            if (grow(l, dl)) { pending = true; break; }   // the next rung would run: left to the probes (lam, dlam stay this rung's)
+        }
         dlam = fmax(dlam * a.sched.mult_lmbda, a.sched.mult_lmbda);  // ilqr.py:166-169
         lam = fmax(lam * dlam, a.sched.min_lmbda);
         // exit every wave reaches: also when lam can no longer grow (max_lmbda = inf, NaN inputs) - the
         // reference's `while not backpass_done` would spin forever there (ilqr.py:162-173)
         if (!(lam <= a.sched.max_lmbda) || !(lam < 1e300) || ++retries >= kMaxLambdaRetries) break;
         wave_lds_fence();
+    }
+    if constexpr (PROBE) {
+        if (div < 0 && lane == 0) atomicMin(ladder_slot, (int)blockIdx.y);
+        return;
+    }
+    if (pending) {
+        if (lane == 0) {
+            io.diverge[p] = -2 - div;
+            io.lmbda[p] = lam;
+            if (io.dlmbda) io.dlmbda[p] = dlam;
+            *ladder_slot = 0x7fffffff;
+        }
+        return;
     }
 
     if (lane == 0) {
@@ -399,6 +454,39 @@ static int launch_sm(const Mf16Args& a, int layout, hipStream_t st) {
         else if (sc) hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, MI, FU, false, true>), grid, block, 0, st, a); \
         else hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, MI, FU, false, false>), grid, block, 0, st, a); \
     } while (0)
+    // The ladder in three launches, for the driver's configuration (gains only, reg = 1, structured cost, retries on).
+    // Inside one wave the rungs of ilqr.py:162-173 are a chain of sweeps, and the launch lasts as long as its slowest
+    // wave: in the early iterations of the C4 workload a handful of problems climb the whole ladder (8 sweeps of ~0.8 ms
+    // each at a lone wave's speed) while 4000 waves have long finished - 8.0 ms a launch where one sweep of everybody
+    // takes 2.4.  So a wave does at most kInKernel retries itself; what still fails is probed, kRungs rungs at once in
+    // as many waves, and resumes at the rung the reference's loop would have stopped at.  Same sweeps on the same
+    // numbers: results are those of mode 0 bit for bit (test_lambda_ladder_in_three_launches_...).
+    // Measured (one box, scripts/debug/c4_ladder_sweep.sh: backward launch of iterations 1 .. 11, then the bench's C4
+    // line): no ladder 8.05 7.96 6.54 6.84 4.41 5.73 3.25 2.63 2.60 2.63 2.55 ms, iteration 8.81 ms; kInKernel = 0:
+    // 5.75 5.41 4.88 5.35 4.79 5.27 4.27 3.04 2.69 2.90 3.20, iteration 8.30; 1: 8.47; 2: 8.65; 3: 9.04.  The early
+    // iterations (what an MPC loop that restarts its solver every control step runs) gain a quarter, the late ones - one
+    // retry for a tenth of the problems, each now probed on 8 rungs - pay ~0.3 ms.  TRAJOPT_NO_LADDER=1 keeps mode 0.
+    constexpr int kRungs = 8;
+    static const bool no_ladder = getenv("TRAJOPT_NO_LADDER") != nullptr;
+    static const int kInKernel = getenv("TRAJOPT_LADDER_INKERNEL") ? atoi(getenv("TRAJOPT_LADDER_INKERNEL")) : 0;   // (experiments)
+    if (a.retry && r1 && sc && !full && a.io.dlmbda && !no_ladder) {
+        Mf16Args a1 = a;
+        a1.mode = 1; a1.inkernel = kInKernel; a1.rungs = kRungs;
+        Mf16Args a2 = a1;
+        a2.mode = 2;
+        const dim3 pgrid((unsigned)a.NP, kRungs);
+        if (minor) {
+            hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, true, false, true, true>), grid, block, 0, st, a1);
+            hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, true, false, true, true, true>), pgrid, block, 0, st, a1);
+            hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, true, false, true, true>), grid, block, 0, st, a2);
+        } else {
+            hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, false, false, true, true>), grid, block, 0, st, a1);
+            hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, false, false, true, true, true>), pgrid, block, 0, st, a1);
+            hipLaunchKernelGGL((bwd_mfma16_kernel<S, M, false, false, true, true>), grid, block, 0, st, a2);
+        }
+        TRAJOPT_HIP_CHECK(hipGetLastError());
+        return TRAJOPT_OK;
+    }
     if (minor && full) TJ_GO(true, true);
     else if (minor) TJ_GO(true, false);
     else if (full) TJ_GO(false, true);
