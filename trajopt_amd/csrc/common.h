@@ -80,6 +80,39 @@ struct RolloutPlanes {
     const int32_t* sel;
 };
 
+// The lambda schedule between iterations (ilqr.py:166-167 / :178-179 and :207-208 / :226-227).
+__device__ __forceinline__ void grow_lambda(double& lam, double& dlam, const trajopt_lambda_schedule_t& s) {
+    dlam = fmax(dlam * s.mult_lmbda, s.mult_lmbda);  // ilqr.py:166 / :226
+    lam = fmax(lam * dlam, s.min_lmbda);             // ilqr.py:167 / :227
+}
+__device__ __forceinline__ void shrink_lambda(double& lam, double& dlam, const trajopt_lambda_schedule_t& s) {
+    dlam = fmin(dlam / s.mult_lmbda, 1.0 / s.mult_lmbda);  // ilqr.py:178 / :207
+    lam = lam * dlam * (lam > s.min_lmbda ? 1.0 : 0.0);    // ilqr.py:179 / :208
+}
+
+// What the driver does per problem right after the backward pass (ilqr.py:175-180, :168 -> :224-231; post_backward_kernel
+// in driver.hip), for a backward kernel that does it itself in the lane that writes the problem's scalars: one launch
+// (~9 us of a 0.68 ms iteration at C2) less.  on = 0: the driver launches post_backward_kernel.
+struct PostBackward {
+    int32_t *ref_plane, *status, *active;
+    double tolgrad;
+    int nb_alphas, wb, on;
+};
+__device__ __forceinline__ void post_backward_problem(const PostBackward& pb, const trajopt_lambda_schedule_t& sched, size_t p,
+                                                      double& lam, double& dlam, double g_norm, int diverge) {
+    const int ref = pb.ref_plane[p];
+    if (ref >= 0 && ref / pb.nb_alphas == pb.wb) pb.ref_plane[p] = -1;
+    if (g_norm < pb.tolgrad && lam < 1e-5) {
+        shrink_lambda(lam, dlam, sched);
+        pb.status[p] = 1;
+        pb.active[p] = 0;
+    } else if (diverge >= 0) {
+        grow_lambda(lam, dlam, sched);
+        if (lam > sched.max_lmbda) pb.status[p] = 3;
+        pb.active[p] = 0;
+    }
+}
+
 // Bank of the multi-buffered gains problem p writes (trajopt_backward_io_t::out_bank), 0 without banks.
 __device__ __forceinline__ int gains_bank(const int32_t* out_bank, size_t p) { return out_bank ? out_bank[p] : 0; }
 

@@ -34,7 +34,7 @@ bool rollout_cost_only_supported(const trajopt_env_t* env, int T, int64_t NP, in
 int backward_kernel_family(int n, int m, int T, int64_t NP, int layout, int want, bool structured);
 int launch_fused_qb4(const trajopt_env_t* env, const trajopt_backward_io_t& io, int reg, int T, int64_t NP, int retry,
                      const trajopt_lambda_schedule_t& sched, const double* xref, const double* uref,
-                     const RefView* rv, hipStream_t st);
+                     const RefView* rv, hipStream_t st, const PostBackward* post);
 
 struct DrvArgs {
     trajopt_ilqr_options_t opt;
@@ -42,14 +42,7 @@ struct DrvArgs {
     int n, m;
 };
 
-__device__ __forceinline__ void grow_lambda(double& lam, double& dlam, const trajopt_lambda_schedule_t& s) {
-    dlam = fmax(dlam * s.mult_lmbda, s.mult_lmbda);  // ilqr.py:166 / :226
-    lam = fmax(lam * dlam, s.min_lmbda);             // ilqr.py:167 / :227
-}
-__device__ __forceinline__ void shrink_lambda(double& lam, double& dlam, const trajopt_lambda_schedule_t& s) {
-    dlam = fmin(dlam / s.mult_lmbda, 1.0 / s.mult_lmbda);  // ilqr.py:178 / :207
-    lam = lam * dlam * (lam > s.min_lmbda ? 1.0 : 0.0);    // ilqr.py:179 / :208
-}
+// (grow_lambda / shrink_lambda, post_backward_problem: common.h)
 
 // dV = [kff'qu, 1/2 kff'Quu kff] (util.cpp:154) of problem p as the backward kernels store it: dV belongs to the gains
 // group, so it is (2, NP) struct-of-arrays for PROBLEM_MINOR and (NP, 2) for PROBLEM_MAJOR.
@@ -105,19 +98,9 @@ __global__ void post_backward_kernel(DrvArgs a, int wb) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (size_t)a.ws.nb_problems) return;
     if (!a.ws.active[p]) return;
-    const int ref = a.ws.ref_plane[p];
-    if (ref >= 0 && ref / a.opt.nb_alphas == wb) a.ws.ref_plane[p] = -1;
+    const PostBackward pb{a.ws.ref_plane, a.ws.status, a.ws.active, a.opt.tolgrad, a.opt.nb_alphas, wb, 1};
     double lam = a.ws.lmbda[p], dlam = a.ws.dlmbda[p];
-    const double g = a.ws.g_norm[p];
-    if (g < a.opt.tolgrad && lam < 1e-5) {
-        shrink_lambda(lam, dlam, a.opt.sched);
-        a.ws.status[p] = 1;
-        a.ws.active[p] = 0;
-    } else if (a.ws.diverge[p] >= 0) {
-        grow_lambda(lam, dlam, a.opt.sched);
-        if (lam > a.opt.sched.max_lmbda) a.ws.status[p] = 3;
-        a.ws.active[p] = 0;
-    }
+    post_backward_problem(pb, a.opt.sched, p, lam, dlam, a.ws.g_norm[p], a.ws.diverge[p]);
     a.ws.lmbda[p] = lam;
     a.ws.dlmbda[p] = dlam;
 }
@@ -475,6 +458,9 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
     const bool fused_lane = may_fuse && !fused_qb && fused_tpp_supported(env, T, NP);
     const int ls = line_search_mode(env, opt, ws);
     const bool staged = ls == 1, two_pass = ls == 2;
+    // the four-problems-per-wave fused kernel also does the per-problem step behind the backward pass (it needs the
+    // gradient norm it computes itself: uref and g_norm given)
+    const bool post_fused = fused_qb && io.uref != nullptr && io.g_norm != nullptr;
     // No copy on accept: the quadratisation reads the reference through ref_plane (time-blocked planes: whole 64-byte
     // runs per problem, whatever planes its neighbours read) and writes what it read through to the dense xref / uref,
     // where the backward kernels' gradient norm and the rollout find it; iteration `it` of this call writes its
@@ -502,7 +488,9 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
             // small batches of dx <= 4, du = 1 models: quadratisation and recursion in one launch, the expansion
             // handed over through LDS (fused_qb4.hip); reported under the "backward" phase
             prof_mark(st, slot, 2);
-            rc = launch_fused_qb4(env, io, opt->reg, T, NP, 1, opt->sched, ws->xref, ws->uref, &rv, st);
+            // (... and what post_backward_kernel does, in the lane that writes a problem's scalars: one launch less)
+            const PostBackward pb{ws->ref_plane, ws->status, ws->active, opt->tolgrad, opt->nb_alphas, wb, post_fused ? 1 : 0};
+            rc = launch_fused_qb4(env, io, opt->reg, T, NP, 1, opt->sched, ws->xref, ws->uref, &rv, st, &pb);
             if (rc != TRAJOPT_OK) return fail(rc);
         } else if (fused_lane) {
             // large batches of the same models: lane = problem, the expansion in registers (bwd_tpp.hip)
@@ -520,7 +508,7 @@ int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t*
         }
         if (!gminor) hipLaunchKernelGGL(gnorm_major_kernel, dim3((unsigned)NP), dim3(64), 0, st, a);
         prof_mark(st, slot, 3);
-        hipLaunchKernelGGL(post_backward_kernel, dim3(g1), dim3(256), 0, st, a, wb);
+        if (!post_fused) hipLaunchKernelGGL(post_backward_kernel, dim3(g1), dim3(256), 0, st, a, wb);
         prof_mark(st, slot, 4);
         if (two_pass) {
             // pass 1: the returns of every (problem, alpha), nothing else written

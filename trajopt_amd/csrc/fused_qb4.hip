@@ -47,6 +47,7 @@ struct FusedArgs {
     RefView rv;                 // rv.ref_plane == nullptr: xref / uref for every problem
     size_t NP;
     int T, retry;
+    PostBackward post;          // post.on: the driver's per-problem step behind the backward pass, done here (common.h)
 };
 
 __device__ __forceinline__ double f4_mm(double a, double b, double c) {
@@ -351,12 +352,14 @@ __global__ __launch_bounds__(256, 1) void fused_qb4_kernel(FusedArgs a) {
         io.diverge[cp] = div;
         io.dV[cp] = dV0;
         io.dV[NP + cp] = dV1;
+        if constexpr (GN) {
+            if (io.g_norm) io.g_norm[cp] = FUSED_DIAG == 4 ? (double)retries : gmax;
+            // post_backward_kernel's step on what this lane holds (post.on implies retry, dlmbda and g_norm: driver.hip)
+            if (a.post.on) post_backward_problem(a.post, a.sched, cp, lam, dlam, gmax, div);
+        }
         if (a.retry) {
             io.lmbda[cp] = lam;
             if (io.dlmbda) io.dlmbda[cp] = dlam;
-        }
-        if constexpr (GN) {
-            if (io.g_norm) io.g_norm[cp] = FUSED_DIAG == 4 ? (double)retries : gmax;
         }
     }
 }
@@ -404,12 +407,14 @@ bool fused_qb4_supported(const trajopt_env_t* env, int T, int64_t NP) {
 // gains-only outputs; A, B, cx, cu, Cxx, Cuu, Cxu are not used.
 int launch_fused_qb4(const trajopt_env_t* env, const trajopt_backward_io_t& io, int reg, int T, int64_t NP, int retry,
                      const trajopt_lambda_schedule_t& sched, const double* xref, const double* uref,
-                     const RefView* rv, hipStream_t st) {
+                     const RefView* rv, hipStream_t st, const PostBackward* post) {
     if (!fused_qb4_supported(env, T, NP) || !io.cost_w) return TRAJOPT_ERR_UNSUPPORTED;
+    if (post && post->on && !(retry && io.dlmbda && io.uref && io.g_norm)) return TRAJOPT_ERR_BAD_ARG;
     FusedLaunch L;
     L.a.env = *env; L.a.io = io; L.a.sched = sched; L.a.xref = xref; L.a.uref = uref;
     L.a.rv = rv ? *rv : RefView{nullptr, nullptr, nullptr, nullptr, nullptr};
     L.a.NP = (size_t)NP; L.a.T = T; L.a.retry = retry;
+    L.a.post = post ? *post : PostBackward{nullptr, nullptr, nullptr, 0.0, 1, 0, 0};
     L.reg = reg; L.gn = io.uref != nullptr && io.g_norm != nullptr; L.done = false; L.st = st;
     if (!dispatch_model(*env, L) || !L.done) return TRAJOPT_ERR_UNSUPPORTED;
     TRAJOPT_HIP_CHECK(hipGetLastError());
