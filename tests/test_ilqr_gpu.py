@@ -387,6 +387,31 @@ def test_batched_mpc_matches_the_reference_loop(oracle):
             x = oracle.env_dynamics(oe, x, u) + noise[p, :, t]
 
 
+@pytest.mark.parametrize("rng_mode", ["given", "device"])
+def test_batched_mpc_as_a_hip_graph_is_bitwise_the_eager_loop(rng_mode):
+    """BatchedMPC.run(graph=True): one control step (re-arm, initial rollout, iterations, plant step) captured once as a
+    HIP graph and replayed per step must give exactly what the eager loop of launches gives - with the kff noise and the
+    process noise handed in, and with both drawn by device generators inside the captured step."""
+    from trajopt_amd import envs
+    from trajopt_amd.mpc import BatchedMPC
+    N, horizon, steps, iters = 70, 24, 5, 4
+    rng = np.random.Generator(np.random.PCG64(9))
+    env = envs.make("cartpole", dt=0.02)
+    x0 = np.asarray(env.x0)[None] + 0.1 * rng.standard_normal((N, 4))
+    outs = []
+    for graph in (False, True):
+        mpc = BatchedMPC(env, horizon, x0, nb_iter=iters, action_penalty=np.array([1e-5]))
+        if rng_mode == "given":
+            kff = 1e-4 * np.random.Generator(np.random.PCG64(3)).standard_normal((steps, N, 1, horizon))
+            noise = 1e-3 * np.random.Generator(np.random.PCG64(4)).standard_normal((N, 4, steps))
+            outs.append(mpc.run(steps, process_noise=noise, kff_inits=kff, graph=graph))
+        else:
+            outs.append(mpc.run(steps, process_noise="env", seed=5, graph=graph))
+    for k in ("state", "action", "cost"):
+        assert np.all(np.isfinite(outs[0][k]))
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
 @pytest.mark.parametrize("name,kw", [("cartpole", dict(dt=0.02)), ("pendulum", dict(dt=0.05))])
 def test_staged_line_search_is_bitwise_the_one_launch_line_search(oracle, name, kw):
     """Scheduling only: alphas[0] for everybody, the rest for the compacted list of rejecting problems
