@@ -458,20 +458,20 @@ static int launch_sm(const Mf16Args& a, int layout, hipStream_t st) {
     // Inside one wave the rungs of ilqr.py:162-173 are a chain of sweeps, and the launch lasts as long as its slowest
     // wave: in the early iterations of the C4 workload a handful of problems climb the whole ladder (8 sweeps of ~0.8 ms
     // each at a lone wave's speed) while 4000 waves have long finished - 8.0 ms a launch where one sweep of everybody
-    // takes 2.4.  So a wave does at most kInKernel retries itself; what still fails is probed, kRungs rungs at once in
+    // takes 2.4.  So a wave does at most `in_wave` retries itself (0 by default); what still fails is probed, kRungs rungs at once in
     // as many waves, and resumes at the rung the reference's loop would have stopped at.  Same sweeps on the same
     // numbers: results are those of mode 0 bit for bit (test_lambda_ladder_in_three_launches_...).
     // Measured (one box, scripts/debug/c4_ladder_sweep.sh: backward launch of iterations 1 .. 11, then the bench's C4
-    // line): no ladder 8.05 7.96 6.54 6.84 4.41 5.73 3.25 2.63 2.60 2.63 2.55 ms, iteration 8.81 ms; kInKernel = 0:
+    // line): no ladder 8.05 7.96 6.54 6.84 4.41 5.73 3.25 2.63 2.60 2.63 2.55 ms, iteration 8.81 ms; in_wave = 0:
     // 5.75 5.41 4.88 5.35 4.79 5.27 4.27 3.04 2.69 2.90 3.20, iteration 8.30; 1: 8.47; 2: 8.65; 3: 9.04.  The early
     // iterations (what an MPC loop that restarts its solver every control step runs) gain a quarter, the late ones - one
     // retry for a tenth of the problems, each now probed on 8 rungs - pay ~0.3 ms.  TRAJOPT_NO_LADDER=1 keeps mode 0.
     constexpr int kRungs = 8;
     static const bool no_ladder = getenv("TRAJOPT_NO_LADDER") != nullptr;
-    static const int kInKernel = getenv("TRAJOPT_LADDER_INKERNEL") ? atoi(getenv("TRAJOPT_LADDER_INKERNEL")) : 0;   // (experiments)
+    static const int in_wave = getenv("TRAJOPT_LADDER_INKERNEL") ? atoi(getenv("TRAJOPT_LADDER_INKERNEL")) : 0;   // (experiments)
     if (a.retry && r1 && sc && !full && a.io.dlmbda && !no_ladder) {
         Mf16Args a1 = a;
-        a1.mode = 1; a1.inkernel = kInKernel; a1.rungs = kRungs;
+        a1.mode = 1; a1.inkernel = in_wave < 0 ? 0 : in_wave; a1.rungs = kRungs;
         Mf16Args a2 = a1;
         a2.mode = 2;
         const dim3 pgrid((unsigned)a.NP, kRungs);

@@ -645,7 +645,7 @@ bool rollout_straight_line(int n, int m, size_t NP, int nb_alphas) {
 #ifndef ROLL_NO_KL
 #define ROLL_NO_KL 0
 #endif
-bool rollout_gains_through_lds(int n, int m, int alpha_minor, int nb_alphas) {
+static bool rollout_gains_through_lds(int n, int m, int alpha_minor, int nb_alphas) {
     return !ROLL_NO_KL && alpha_minor && nb_alphas >= 8 && n + m > 8 && (n * m) % 16 == 0;
 }
 
