@@ -387,6 +387,35 @@ def test_batched_mpc_matches_the_reference_loop(oracle):
             x = oracle.env_dynamics(oe, x, u) + noise[p, :, t]
 
 
+def test_batched_mpc_with_shift_warm_start_matches_the_same_loop_on_the_oracle(oracle):
+    """SURVEY 8f.1's receding-horizon loop with the shift warm start (BatchedMPC.run(warm_start=True)): from the second
+    control step on every solve starts from the previous plan shifted by one step (last action repeated) as its initial
+    feed-forward - against the oracle's iLQR run in the same loop."""
+    from trajopt_amd import envs
+    from trajopt_amd.mpc import BatchedMPC
+    N, horizon, steps, iters = 7, 20, 6, 4
+    rng = np.random.Generator(np.random.PCG64(17))
+    env = envs.make("Pendulum-TO-v0")
+    env.unwrapped.dt = 0.05
+    x0 = np.array([np.pi, 0.])[None] + 0.05 * rng.standard_normal((N, 2))
+    kff = 1e-4 * rng.standard_normal((1, N, 1, horizon))
+    noise = 1e-3 * rng.standard_normal((N, 2, steps))
+    mpc = BatchedMPC(env, horizon, x0, nb_iter=iters, action_penalty=np.array([1e-5]))
+    out = mpc.run(steps, process_noise=noise, kff_inits=np.repeat(kff, steps, axis=0), warm_start=True)
+    oe = oracle.make_env("pendulum", dt=0.05, uw=[1e-5])
+    for p in range(N):
+        x = x0[p].copy()
+        k0 = kff[0, p]
+        for t in range(steps):
+            r = oracle.ilqr_run(oe, horizon, x, k0, nb_iter=iters)
+            u = r["uref"][:, 0]
+            assert_close(out["state"][p, :, t], x, "state[%d,%d]" % (p, t), tol=1e-7)
+            assert abs(out["action"][p, 0, t] - u[0]) <= 1e-7 * max(1.0, abs(u[0])), (p, t)
+            assert abs(out["cost"][p, t] - r["last_return"]) <= 1e-8 * abs(r["last_return"])
+            x = oracle.env_dynamics(oe, x, u) + noise[p, :, t]
+            k0 = np.concatenate((r["uref"][:, 1:], r["uref"][:, -1:]), axis=1)
+
+
 @pytest.mark.parametrize("rng_mode", ["given", "device"])
 def test_batched_mpc_as_a_hip_graph_is_bitwise_the_eager_loop(rng_mode):
     """BatchedMPC.run(graph=True): one control step (re-arm, initial rollout, iterations, plant step) captured once as a

@@ -46,13 +46,18 @@ class BatchedMPC:
                                                        _lib.dptr(xn), None, _lib.stream_ptr()))
         return xn
 
-    def run(self, nb_steps, process_noise=None, kff_inits=None, seed=1337, kff_rng="device", to_host=True, graph=False):
+    def run(self, nb_steps, process_noise=None, kff_inits=None, seed=1337, kff_rng="device", to_host=True, graph=False,
+            warm_start=False):
         """-> dict(state (N, n, nb_steps + 1), action (N, m, nb_steps), cost (N, nb_steps): last accepted return of
         each horizon solve).  kff_inits: optional (nb_steps, N, m, horizon) initial feed-forward noise per solve.
         Without it every solve draws 1e-4 * randn as a fresh reference solver does (ilqr.py:70): kff_rng = "device"
         (default) from a torch generator ON THE GPU (seeded with `seed`; no host work, no upload - at 65 536 cartpoles x
         T = 500 the host draw is 262 MB per control step), kff_rng = "numpy" from np.random as the reference (to
         reproduce a reference run's stream).  to_host=False returns the device tensors (T-major, PROBLEM_MINOR).
+        warm_start=True (SURVEY 8f.1's "shift warm-start"; the reference's scripts start every solve cold): from the second
+        control step on a solve starts from the previous plan shifted by one step - kff_init[t] = uref_prev[t + 1], the last
+        action repeated - instead of fresh noise; K = 0 and uref = 0 as in a fresh solver, so the initial rollout
+        (ilqr.py:139-149) applies exactly that shifted plan.  Device work only (a slice copy of uref).
         graph=True: ONE control step - re-arm, initial rollout, nb_iter iterations, plant step: ~45 kernel launches, which
         at short horizons (the examples use 60) are most of its time - is captured once as a HIP graph (torch.cuda.CUDAGraph
         around the library's launches on the capture stream: nothing in that path allocates or synchronises) and replayed
@@ -85,6 +90,8 @@ class BatchedMPC:
             chol = torch.as_tensor(np.linalg.cholesky(np.asarray(self.env.unwrapped.sigma, dtype=np.float64)), device=dev)
         elif process_noise is not None:
             process_noise = torch.as_tensor(np.asarray(process_noise, dtype=np.float64), device=dev)  # (N, n, steps)
+        assert not (warm_start and graph), "warm_start changes what a step starts from: use the eager loop"
+        warm = None   # (N, m, horizon) logical view of the shifted previous plan
         if graph:
             assert kff_inits is not None or kff_rng == "device", "graph=True draws the kff noise on the device"
             x_cur = state[0].clone()
@@ -122,11 +129,18 @@ class BatchedMPC:
                 state[t + 1].copy_(x_cur)
             nb_steps = 0   # (the eager loop below has nothing left to do)
         for t in range(nb_steps):
-            s.reset(state[t].t(), None if kff_inits is None else kff_inits[t], generator=kgen)
+            if warm is not None:
+                s.reset(state[t].t(), warm, generator=None)
+            else:
+                s.reset(state[t].t(), None if kff_inits is None else kff_inits[t], generator=kgen)
             s.init_rollout()
             s.iterate(self.nb_iter)
             action[t] = s.uref[0]
             cost[t] = s.last_return
+            if warm_start:
+                # uref is (horizon, m, N) on the device: the plan from its second action on, the last one twice
+                shifted = torch.cat((s.uref[1:], s.uref[-1:]), dim=0)
+                warm = shifted.permute(2, 1, 0)
             xn = self._plant(state[t].contiguous(), action[t].contiguous())
             if gen is not None:
                 xn = xn + chol @ torch.randn((n, N), dtype=torch.float64, device=dev, generator=gen)
