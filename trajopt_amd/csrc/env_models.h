@@ -172,16 +172,22 @@ template <> struct Model<TRAJOPT_ENV_CARTPOLE> {
     template <class X> static __device__ __forceinline__ void f(const trajopt_env_t& e, const X (&x)[N], const X (&u)[M], X (&dx)[N]) {
         const double g = e.phys[0], Mc = e.phys[1], Mp = e.phys[2], l = e.phys[3], fr = e.phys[4];
         const double Mt = Mc + Mp, iMt = 1.0 / Mt;   // loop-invariant: hoisted out of the time loop
+        // cartpole.py:62-97 with 1 / Mt folded into the constants (every instruction of this chain is paid for in full by a
+        // lone wave: 12 fewer a step than the expressions as written, same values to round-off):
+        //   num = g sin + cos (-(u - fr dq) - Mp l dth^2 sin) / Mt,  den = l (4/3 - Mp cos^2 / Mt) > 0
+        const double friMt = fr * iMt, MpliMt = (Mp * l) * iMt, kl = l * (Mp * iMt), l43 = l * (4.0 / 3.0);
         X sth, cth;
         sincos_g(x[1], sth, cth);
         const X dq = x[2], dth = x[3];
+        const X uim = u[0] * iMt;               // (the same value in all four RK4 stages: computed once)
         const X dth2s = dth * dth * sth;
-        const X num = g * sth + cth * (-(u[0] - fr * dq) - (Mp * l) * dth2s) * iMt;
-        const X den = l * ((4.0 / 3.0) - (Mp * iMt) * cth * cth);
-        const X ddth = num * recip_pos(den);   // den = l (4/3 - Mp cos^2 / Mt) > 0
+        const X b = (friMt * dq - uim) - MpliMt * dth2s;
+        const X num = g * sth + cth * b;
+        const X den = l43 - (kl * cth) * cth;
+        const X ddth = num * recip_pos(den);
         dx[0] = dq;
         dx[1] = dth;
-        dx[2] = (u[0] + (Mp * l) * (dth2s - ddth * cth)) * iMt;
+        dx[2] = uim + MpliMt * (dth2s - ddth * cth);
         dx[3] = ddth;
     }
 };
