@@ -544,7 +544,7 @@ def main():
         }
         if devices is not None:
             out["rank_devices"] = devices
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # (the CPU baseline is a rank-0, N = 1 leg: a scaling run does not repeat it)
             dt, uw = ENV_DEFAULTS[a.env]
             cb = cpu_baseline(a.env, dt, uw, T, 1337, a.cpu_budget)
             out["cpu_baseline"] = rounded(cb)
