@@ -15,6 +15,7 @@
 //                    double pendulum {g, m1, m2, l1, l2, k1, k2}.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace trajopt {
 
@@ -202,7 +203,15 @@ template <> struct Model<TRAJOPT_ENV_DOUBLE_CARTPOLE> {
         X s1, c1, s2, c2, sd, cd;
         sincos_g(x[1], s1, c1);
         sincos_g(x[2], s2, c2);
-        sincos_g(x[1] - x[2], sd, cd);
+        // sin / cos of th1 - th2 (double_cartpole.py:61-187 takes them of the difference): for plain numbers from the
+        // subtraction identities - four instructions instead of a third sincos of 27, a seventh of the rollout's step, at
+        // an absolute error of ~1e-15; for dual numbers four products of duals would cost more than the sincos does
+        if constexpr (std::is_same<X, double>::value) {
+            sd = s1 * c2 - c1 * s2;
+            cd = c1 * c2 + s1 * s2;
+        } else {
+            sincos_g(x[1] - x[2], sd, cd);
+        }
         const X dth1 = x[4], dth2 = x[5];
         // symmetric inertia matrix  [[Mt, m12, m13], [m12, m22, m23], [m13, m23, m33]]
         const X m12 = a * c1, m13 = b * c2, m23 = d * cd;
