@@ -217,9 +217,13 @@ class Ctx:
         self.torch.cuda.empty_cache()
 
 
-def iteration_line(cx, env_name, N, T, alphas, K, W, seed, staged=-1, no_fusion=False, max_lmbda=float("inf")):
+def iteration_line(cx, env_name, N, T, alphas, K, W, seed, staged=-1, no_fusion=False, max_lmbda=float("inf"), sub_batches=1):
     """W untimed + K timed iLQR iterations of N problems on this rank -> measurements (all ranks take part in the
     fences; the elapsed time is the max over ranks).
+    sub_batches: 1 = one batch on one stream; S > 1 (0: the solver's own rule, trajopt_amd/ilqr/streamed.py) = after
+    that measurement the SAME problems once more as S sub-batches on streams of their own (StreamedILQR), W untimed +
+    K timed iterations -> out["streamed"]; phases and the dominant kernel's time always come from the one-batch run
+    (launches of different sub-batches overlap: per-kernel times are not separable there).
     max_lmbda: inf = no problem ever gives up (the headline's setting: constant work per step); the reference's
     default 1e6 lets a problem whose backward pass cannot be regularised stop as ilqr.py:168,228 does - the line then
     counts ONLY the problem-iterations that were executed (`problem_iters`)."""
@@ -230,9 +234,9 @@ def iteration_line(cx, env_name, N, T, alphas, K, W, seed, staged=-1, no_fusion=
     env = envs.make(env_name, dt=dt, uw=uw)
     n, m = env.dm_state, env.dm_act
     x0, kff0 = make_problem_set(env, N, T, seed)
-    solver = BatchedILQR(env, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False, alphas=alphas,
-                         tolfun=-float("inf"), tolgrad=0.0, max_lmbda=max_lmbda, staged_line_search=staged,
-                         no_fusion=no_fusion, trace_cap=W + K + 16)
+    skw = dict(action_penalty=None, apply_env_kwargs=False, alphas=alphas, tolfun=-float("inf"), tolgrad=0.0,
+               max_lmbda=max_lmbda, staged_line_search=staged, no_fusion=no_fusion, trace_cap=W + K + 16)
+    solver = BatchedILQR(env, T, x0, kff_init=kff0, **skw)
     del x0, kff0
 
     def profiled(iters, mask=None):
@@ -290,6 +294,28 @@ def iteration_line(cx, env_name, N, T, alphas, K, W, seed, staged=-1, no_fusion=
            "mean_return": float(ret[status == 0].mean())}
     del solver
     cx.release()
+    from trajopt_amd.ilqr import StreamedILQR, auto_sub_batches
+    S = auto_sub_batches(n, m, N) if sub_batches == 0 else int(sub_batches)
+    if S > 1:
+        x0, kff0 = make_problem_set(env, N, T, seed)
+        sub = StreamedILQR(env, T, x0, kff_init=kff0, sub_batches=S, **skw)
+        del x0, kff0
+        sub.init_rollout()
+        sub.iterate(W)
+        iters0 = sub.host("iters").astype(np.int64)
+        cx.fence()
+        t0 = time.perf_counter()
+        sub.iterate(K)
+        cx.fence()
+        t1 = time.perf_counter()
+        iters1, status, ret = sub.host("iters").astype(np.int64), sub.host("status"), sub.host("last_return")
+        if max_lmbda == float("inf"):
+            assert np.all(status == 0) and np.all(iters1 == W + K), "a problem stopped inside the timed region"
+            assert np.all(np.isfinite(ret)), "non-finite trajectory cost"
+        out["streamed"] = {"sub_batches": S, "elapsed": cx.max_over_ranks(t1 - t0), "problem_iters": int((iters1 - iters0).sum()),
+                           "gave_up": int((status == 3).sum()), "mean_return": float(ret[status == 0].mean())}
+        del sub
+        cx.release()
     return out
 
 
@@ -343,15 +369,21 @@ def config_line(r, world, stamp, label):
     """One entry of `configs` for an iteration line."""
     roof = roofline_of(r, stamp)
     keep = ("bound", "kernel", "achieved", "unit", "frac", "avg_launch_ms")
-    out = {"workload": label, "n_gpus": world, "steps": r["K"], "ms": r["elapsed"] / r["K"] * 1e3,
+    t = r.get("streamed", r)   # the timed run that counts: the sub-batched one where the solver's rule takes it
+    out = {"workload": label, "n_gpus": world, "steps": r["K"], "ms": t["elapsed"] / r["K"] * 1e3,
            # problem-timesteps/s over the problem-iterations actually executed in the timed region (= N K unless a problem gave up)
-           "value": world * r["problem_iters"] * r["T"] / r["elapsed"],
+           "value": world * t["problem_iters"] * r["T"] / t["elapsed"],
            "roofline": {k: roof[k] for k in keep if k in roof},
            "phase_ms": {k: r["phases"][k] for k in KERNEL_PHASES},
            "backward_frac_of_hbm": backward_of(r)["frac_of_hbm_peak"],
            "plan": {k: v for k, v in r["plan"].items() if k != "pad_"}}
-    if r["gave_up"]:
-        out["problem_iters"], out["gave_up"] = r["problem_iters"], r["gave_up"]
+    if "streamed" in r:
+        out["sub_batches"] = t["sub_batches"]
+        out["one_batch"] = {"ms": r["elapsed"] / r["K"] * 1e3, "value": world * r["problem_iters"] * r["T"] / r["elapsed"],
+                            "note": "the same problems and iterations as ONE batch on one stream; roofline and phase_ms are "
+                                    "taken on this run (launches of different sub-batches overlap)"}
+    if t["gave_up"]:
+        out["problem_iters"], out["gave_up"] = t["problem_iters"], t["gave_up"]
     return out
 
 
@@ -431,6 +463,9 @@ def main():
     ap.add_argument("--no-fusion", action="store_true", help="quadratise and backward pass as two launches (same results)")
     ap.add_argument("--max-lmbda", type=float, default=float("inf"),
                     help="headline line only: the reference's give-up rule (ilqr.py:17 uses 1e6); inf = every problem iterates in every step")
+    ap.add_argument("--sub-batches", type=int, default=1,
+                    help="headline line: 1 = one batch on one stream (default); S > 1 = the problems as S sub-batches on HIP streams of "
+                         "their own (StreamedILQR); 0 = the solver's rule (1 at C2).  The configs block always takes the rule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="the headline line only")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -481,26 +516,27 @@ def main():
     N, T, K, W = a.instances, a.horizon, a.steps, a.warmup
     alphas = ALL_ALPHAS[:a.alphas]
     cx = Ctx(torch, _lib.lib(), dist, red_dev, rank, world)
-    r = iteration_line(cx, a.env, N, T, alphas, K, W, 1337 + rank, staged=a.staged, no_fusion=a.no_fusion, max_lmbda=a.max_lmbda)
+    r = iteration_line(cx, a.env, N, T, alphas, K, W, 1337 + rank, staged=a.staged, no_fusion=a.no_fusion, max_lmbda=a.max_lmbda,
+                       sub_batches=a.sub_batches)
     stamp = _lib.source_stamp()
     n, m = r["n"], r["m"]
 
     configs = {}
     if not a.no_configs:
         # C3: every rank its share of 8192 double cartpoles (world x 8192 problems, no collective) - at any world size
-        c3 = iteration_line(cx, "double_cartpole", 8192, 500, ALL_ALPHAS, 10, 3, 4001 + rank)
+        c3 = iteration_line(cx, "double_cartpole", 8192, 500, ALL_ALPHAS, 10, 3, 4001 + rank, sub_batches=0)
         configs["c3_share"] = config_line(c3, world, stamp, "C3: 8192 double cartpoles per GPU (dx=6 du=1 T=500, 11 alphas), %d GPU(s)" % world)
         if world == 1:   # single-GPU workloads
-            q = iteration_line(cx, "cartpole", 65536, 500, ALL_ALPHAS, 10, 3, 2001)
+            q = iteration_line(cx, "cartpole", 65536, 500, ALL_ALPHAS, 10, 3, 2001, sub_batches=0)
             configs["cartpole_65536"] = config_line(q, 1, stamp, "north_star target: 65 536 cartpoles on one GPU (dx=4 du=1 T=500, 11 alphas)")
             # C4 twice.  The start (free fall under kff = 1e-4 randn, ilqr.py:70) sends ~4 % of the quadrotors tumbling
             # through the Euler-angle singularity; their backward pass overflows for every lambda the reference allows.
             # (a) max_lmbda = 1e6, the reference's default: such a problem gives up as ilqr.py:168,228 says and only
             # executed problem-iterations count; (b) nothing ever gives up (the headline's rule): each of them then
             # takes ~54 growing-lambda sweeps per iteration until lambda overflows, and the launch waits for them.
-            q = iteration_line(cx, "quadrotor", 4096, 500, ALL_ALPHAS[:8], 8, 3, 3001, max_lmbda=1e6)
+            q = iteration_line(cx, "quadrotor", 4096, 500, ALL_ALPHAS[:8], 8, 3, 3001, max_lmbda=1e6, sub_batches=0)
             configs["c4_quadrotor"] = config_line(q, 1, stamp, "C4: 4096 quadrotors (dx=12 du=4 T=500), 8 alphas, max_lmbda=1e6 (reference default): hopeless problems give up, only executed problem-iterations counted")
-            q = iteration_line(cx, "quadrotor", 4096, 500, ALL_ALPHAS[:8], 8, 3, 3001)
+            q = iteration_line(cx, "quadrotor", 4096, 500, ALL_ALPHAS[:8], 8, 3, 3001, sub_batches=0)
             configs["c4_quadrotor_never_give_up"] = config_line(q, 1, stamp, "C4 with max_lmbda=inf: every problem iterates in every step")
             configs["c5_riccati"] = riccati_line(cx)
             configs["backward_dense"] = {
@@ -523,12 +559,13 @@ def main():
         # kernel sources are the ones they were collected from (stamp)
         pmc = stamped("r03_pmc_traffic_c2.json", stamp) if is_c2 else None
         sq = stamped("r03_pmc_sq_c2.json", stamp) if is_c2 else None
+        timed = r.get("streamed", r)
         out = {
             "metric": "problem-timesteps/sec (iLQR iteration, batched)",
-            "value": world * N * T * K / r["elapsed"],
+            "value": world * N * T * K / timed["elapsed"],
             "unit": "problem-timesteps/s",
             "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": r["elapsed"] / K * 1e3,
+            "ms_per_step": timed["elapsed"] / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: batched iLQR %s dx=%d du=%d T=%d, %d instances per GPU, %d alphas, reg=1, "
@@ -542,6 +579,11 @@ def main():
             "source_stamp": stamp,
             "mean_return": r["mean_return"],
         }
+        if "streamed" in r:
+            out["sub_batches"] = timed["sub_batches"]
+            out["one_batch_ms_per_step"] = r["elapsed"] / K * 1e3
+            out["sub_batches_note"] = ("ms_per_step / value: the problems as sub-batches on HIP streams of their own; roofline, phase_ms and "
+                                       "one_batch_ms_per_step: the same problems and iterations as one batch on one stream")
         if devices is not None:
             out["rank_devices"] = devices
         if not a.no_cpu_baseline and world == 1:   # (the CPU baseline is a rank-0, N = 1 leg: a scaling run does not repeat it)

@@ -449,7 +449,11 @@ int trajopt_ilqr_init_rollout(const trajopt_env_t* env, const trajopt_ilqr_optio
                               const trajopt_ilqr_workspace_t* ws, void* stream);
 /* `nb_iter` iterations of ilqr.py:151-231 for every problem whose status is 0, without any host
  * synchronisation: quadratise -> backward pass with in-kernel lambda retries -> gradient-norm stop ->
- * rollout over all alphas -> first-accept selection -> accept/reject and lambda update. */
+ * rollout over all alphas -> first-accept selection -> accept/reject and lambda update.
+ * The call keeps no state outside `ws`: calls on DIFFERENT workspaces may overlap on different streams of one GPU (while no
+ * trajopt_profile_begin is open).  Problems are independent, so a batch can be cut into a few workspaces that iterate side
+ * by side - one's rollout under another's backward pass; measured gains and the rule the Python host side uses:
+ * trajopt_amd/ilqr/streamed.py. */
 int trajopt_ilqr_iterate(const trajopt_env_t* env, const trajopt_ilqr_options_t* opt,
                          const trajopt_ilqr_workspace_t* ws, int nb_iter, void* stream);
 

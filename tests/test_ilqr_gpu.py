@@ -667,3 +667,44 @@ def test_mpc_with_device_drawn_kff_noise_is_reproducible_and_stays_on_the_device
     g.manual_seed(1)
     s.reset(torch.as_tensor(x0, device=s.device), generator=g)
     assert np.array_equal(k, s.host("kff"))
+
+
+@pytest.mark.parametrize("name,N,T,iters,S,kw", [
+    ("cartpole", 301, 21, 4, 3, dict(dt=0.02, uw=[1e-5])),          # uneven split: 101 + 100 + 100
+    ("double_cartpole", 64, 30, 3, 2, dict(dt=0.01, uw=[1e-5])),
+    ("quadrotor", 48, 24, 2, 4, dict(dt=0.02)),                      # PROBLEM_MAJOR gains group, lambda ladder
+])
+def test_sub_batches_on_streams_solve_every_problem_as_the_oracle_and_as_one_batch(oracle, name, N, T, iters, S, kw):
+    """StreamedILQR (trajopt_amd/ilqr/streamed.py): the batch as S sub-batches, each a BatchedILQR on a HIP stream of its
+    own - problems are independent (ilqr.py:136-237 runs one), so every problem must come out as from one batch (same
+    kernels at these sizes: bit for bit) and as from the oracle's driver, in problem order, stopping rules armed."""
+    from trajopt_amd.ilqr import BatchedILQR, StreamedILQR
+    pe, oe = _pair(name, **kw)
+    rng = np.random.Generator(np.random.PCG64(77))
+    x0 = np.asarray(pe.x0)[None] + 1e-2 * rng.standard_normal((N, pe.dm_state))
+    kff0 = 1e-3 * rng.standard_normal((N, pe.dm_act, T))
+    one = BatchedILQR(pe, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False)
+    t_one = one.run(nb_iter=iters)
+    sub = StreamedILQR(pe, T, x0, kff_init=kff0, sub_batches=S, action_penalty=None, apply_env_kwargs=False)
+    assert sub.sub_batches == S and len(sub.parts) == S and sub.bounds[-1] == N
+    assert sub.plan()["sub_batches"] == S
+    t_sub = sub.run(nb_iter=iters)
+    assert t_sub == t_one
+    for k in ("xref", "uref", "K", "kff", "lmbda", "dlmbda", "status", "iters", "last_return"):
+        assert np.array_equal(sub.host(k), one.host(k)), k
+    for p in list(range(0, N, max(1, N // 7))) + [N - 1]:
+        r = oracle.ilqr_run(oe, T, x0[p], kff0[p], nb_iter=iters)
+        assert len(t_sub[p]) == len(r["trace"]), (p, t_sub[p], r["trace"])
+        assert_close(np.array(t_sub[p]), r["trace"], "trace[%d]" % p)
+        assert_close(sub.host("xref")[p], r["xref"], "xref", tol=1e-8)
+        assert_close(sub.host("uref")[p], r["uref"], "uref", tol=1e-8)
+    # a second solve after reset(), without reallocating: iterate() is asynchronous, host() waits for the side streams
+    x1 = x0 + 1e-2 * rng.standard_normal(x0.shape)
+    sub.reset(x1, kff0)
+    one.reset(x1, kff0)
+    sub.init_rollout()
+    one.init_rollout()
+    sub.iterate(iters)
+    one.iterate(iters)
+    for k in ("xref", "uref", "last_return", "iters", "status"):
+        assert np.array_equal(sub.host(k), one.host(k)), k

@@ -76,3 +76,18 @@ def test_plan_rejects_an_incomplete_workspace():
     ws.nb_steps, ws.nb_problems, ws.gains_layout, ws.trace_cap = 10, 4, 1, 4
     o.nb_alphas = 2
     assert L.trajopt_ilqr_plan(C.byref(st), C.byref(o), C.byref(ws), C.byref(pl)) == -1   # TRAJOPT_ERR_BAD_ARG
+
+
+def test_sub_batch_rule_and_split():
+    """trajopt_amd/ilqr/streamed.py: how many sub-batches a batch is cut into by default (the measured table in its
+    docstring) and how the problems are dealt out - contiguous, as equal as possible, every problem exactly once."""
+    from trajopt_amd.ilqr.streamed import auto_sub_batches, split_sizes
+    assert auto_sub_batches(4, 1, 4096) == 1 and auto_sub_batches(4, 1, 16384) == 1 and auto_sub_batches(4, 1, 65536) == 1
+    assert auto_sub_batches(2, 1, 65536) == 1 and auto_sub_batches(2, 1, 1) == 1
+    assert auto_sub_batches(6, 1, 4096) == 1 and auto_sub_batches(6, 1, 8192) == 2 and auto_sub_batches(6, 1, 16384) == 4
+    assert auto_sub_batches(6, 1, 65536) == 1
+    assert auto_sub_batches(12, 4, 4096) == 4 and auto_sub_batches(12, 4, 512) == 1
+    for N, S in ((301, 3), (8192, 2), (7, 7), (10, 4), (1, 1)):
+        sizes = split_sizes(N, S)
+        assert len(sizes) == S and sum(sizes) == N and max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+        assert sizes == sorted(sizes, reverse=True)
