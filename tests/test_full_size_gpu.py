@@ -168,8 +168,10 @@ def test_ilqr_iteration_full_size_c4_eight_alphas(oracle):
     assert s.alphas.size == 8 and s._cand_state.shape[0] == 17
 
 
-def test_sharded_ilqr_world_size_one_is_the_batched_solver(oracle):
-    """ShardedILQR without a process group = BatchedILQR on the whole batch, bit for bit."""
+@pytest.mark.parametrize("sub", [None, 3])
+def test_sharded_ilqr_world_size_one_is_the_batched_solver(oracle, sub):
+    """ShardedILQR without a process group = BatchedILQR on the whole batch, bit for bit - also when the rank runs its
+    block as sub-batches on streams of their own (sub = 3; None: the rule, one batch at this size)."""
     from trajopt_amd import envs
     from trajopt_amd.ilqr import BatchedILQR
     from trajopt_amd.sharding import ShardedILQR
@@ -177,7 +179,8 @@ def test_sharded_ilqr_world_size_one_is_the_batched_solver(oracle):
     rng = np.random.Generator(np.random.PCG64(5))
     x0 = np.array([0., np.pi, 0., 0.])[None] + 1e-2 * rng.standard_normal((N, 4))
     kff0 = 1e-4 * rng.standard_normal((N, 1, T))
-    sh = ShardedILQR(envs.make("cartpole", dt=0.02), T, x0, kff_init=kff0, action_penalty=1e-5)
+    sh = ShardedILQR(envs.make("cartpole", dt=0.02), T, x0, kff_init=kff0, action_penalty=1e-5, sub_batches=sub)
+    assert sh.local.sub_batches == (sub or 1)
     out = sh.run(nb_iter=iters)
     b = BatchedILQR(envs.make("cartpole", dt=0.02), T, x0, kff_init=kff0, action_penalty=1e-5)
     b.run(nb_iter=iters)

@@ -164,6 +164,14 @@ class StreamedILQR:
                 np.bincount(st, minlength=4).tolist()))
         return traces
 
+    def vector(self, name):
+        """Device tensor (N,) of a per-problem vector (last_return, status, iters, lmbda ...) of the whole batch, in problem
+        order, on the caller's stream (a copy unless the batch is one sub-batch)."""
+        import torch
+        self._join()
+        vs = [getattr(part, name) for part in self.parts]
+        return vs[0] if len(vs) == 1 else torch.cat(vs)
+
     def host(self, name):
         """Logical NumPy array (N, rows[, cols], T) or (N,) vector of the whole batch, in problem order."""
         self.synchronize()

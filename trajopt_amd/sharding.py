@@ -79,12 +79,14 @@ def reduce_progress(last_return, status, lmbda, group=None):
 
 
 class ShardedILQR:
-    """N problems split over the ranks of the default process group; each rank runs a BatchedILQR on its block
-    on its own GPU.  `init_state` (N, dm_state) and `kff_init` (N, dm_act, T) are the GLOBAL arrays (every
-    rank passes the same ones and slices its block), so results do not depend on the number of GPUs."""
+    """N problems split over the ranks of the default process group; each rank runs its block on its own GPU - as
+    one BatchedILQR or, where that is faster (larger models: trajopt_amd/ilqr/streamed.py; `sub_batches` None = its rule,
+    1 = never), as a few sub-batches on HIP streams of their own.  `init_state` (N, dm_state) and `kff_init` (N, dm_act, T)
+    are the GLOBAL arrays (every rank passes the same ones and slices its block), so results do not depend on the number
+    of GPUs."""
 
-    def __init__(self, env, nb_steps, init_state, kff_init=None, **kw):
-        from .ilqr import BatchedILQR
+    def __init__(self, env, nb_steps, init_state, kff_init=None, sub_batches=None, **kw):
+        from .ilqr import StreamedILQR
         dist = _dist()
         self.world = dist.get_world_size() if dist else 1
         self.rank = dist.get_rank() if dist else 0
@@ -94,15 +96,16 @@ class ShardedILQR:
         if kff_init is None:
             rng = np.random.Generator(np.random.PCG64(1337))
             kff_init = 1e-4 * rng.standard_normal((self.nb_problems, env.unwrapped.dm_act, nb_steps))
-        self.local = BatchedILQR(env, nb_steps, init_state[self.lo:self.hi],
-                                 kff_init=np.asarray(kff_init)[self.lo:self.hi], **kw)
+        self.local = StreamedILQR(env, nb_steps, init_state[self.lo:self.hi],
+                                  kff_init=np.asarray(kff_init)[self.lo:self.hi], sub_batches=sub_batches, **kw)
 
     def run(self, nb_iter=25):
         """Runs the local block, then gathers -> dict(last_return, status, iters) of all N problems + progress."""
         self.local.run(nb_iter=nb_iter)
         b = self.local
-        out = dict(last_return=gather_problem_vector(b.last_return, self.nb_problems),
-                   status=gather_problem_vector(b.status, self.nb_problems),
-                   iters=gather_problem_vector(b.iters, self.nb_problems))
-        out["progress"] = reduce_progress(b.last_return, b.status, b.lmbda)
+        last_return, status = b.vector("last_return"), b.vector("status")
+        out = dict(last_return=gather_problem_vector(last_return, self.nb_problems),
+                   status=gather_problem_vector(status, self.nb_problems),
+                   iters=gather_problem_vector(b.vector("iters"), self.nb_problems))
+        out["progress"] = reduce_progress(last_return, status, b.vector("lmbda"))
         return out
