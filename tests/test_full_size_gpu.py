@@ -416,7 +416,10 @@ def test_bench_collective_path_with_rccl_at_world_size_one():
     env = dict(os.environ, TRAJOPT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--instances", "512",
-                        "--horizon", "48", "--no-configs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+                        "--horizon", "48", "--no-configs", "--no-cpu-baseline", "--sub-batches", "2"],
+                       capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and len(d["rank_devices"]) == 1 and d["value"] > 0
+    # (--sub-batches 2: the timed run is the sub-batched one - side streams next to RCCL's own - and the one-batch time rides along)
+    assert d["sub_batches"] == 2 and d["one_batch_ms_per_step"] > 0

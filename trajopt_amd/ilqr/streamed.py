@@ -36,18 +36,65 @@ def split_sizes(nb_problems, parts):
     return [q + 1 if i < r else q for i in range(int(parts))]
 
 
-_SIDE_STREAMS = {}   # device index -> side streams, made once per process and shared by every StreamedILQR
+_SIDE_STREAMS = {}   # device index -> side streams, chosen once per process and shared by every StreamedILQR
+_PROBE_CYCLES = 400_000      # ~0.2 ms of torch.cuda._sleep
+_PROBE_CANDIDATES = 12
+
+
+def _concurrent(torch, streams, one):
+    """Do one-wave spins on `streams`, started together, take about as long as one of them (`one` ms)?"""
+    import time
+    best = float("inf")
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(_PROBE_CYCLES)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) * 1e3)
+    return best < 1.6 * one
 
 
 def side_streams(device, count):
-    """`count` side streams of `device`.  They are made once per process: the runtime deals HIP streams out over
-    GPU_MAX_HW_QUEUES (4) hardware queues, and two sub-batches whose streams share a queue run one after the other (measured:
-    4096 quadrotors 9.4 - 9.8 ms an iteration instead of 6.1 - 6.9, worse than the 7.8 of one batch) - with fresh
-    streams for every solver that happened in one run of eight."""
+    """Up to `count` side streams of `device` that run CONCURRENTLY with the current stream and with each other.
+
+    The runtime deals HIP streams out over GPU_MAX_HW_QUEUES (4) hardware queues, round robin over every stream the
+    process makes (RCCL's included), and two streams on one queue run their kernels one after the other: sub-batches on
+    such a pair are slower than one batch (measured: 4096 quadrotors 9.4 - 9.8 ms an iteration instead of 6.1 - 6.4, one
+    batch 7.8; with fresh streams per solver that happened in every bench.py process and in one of eight runs of a loop,
+    with RCCL initialised in most).  So the streams are CHOSEN, once per process: candidates from torch's pool are tried
+    with a one-wave spin (torch.cuda._sleep) next to the current stream and the streams already chosen - together they must
+    take about as long as one spin alone (scripts/debug/stream_probe.py shows the pattern: every fourth stream collides).
+    Fewer than `count` may come back (the caller then makes fewer sub-batches)."""
+    import time
     import torch
-    have = _SIDE_STREAMS.setdefault(torch.device(device).index, [])
-    while len(have) < count:
-        have.append(torch.cuda.Stream(device=device))
+    dev = torch.device(device)
+    have = _SIDE_STREAMS.get(dev.index)
+    if have is None:
+        have = []
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            cands = [torch.cuda.Stream(device=dev) for _ in range(_PROBE_CANDIDATES)]
+            if hasattr(torch.cuda, "_sleep"):
+                for st in [cur] + cands:          # first use of a stream binds its queue: not part of the timing
+                    with torch.cuda.stream(st):
+                        torch.cuda._sleep(1000)
+                one = float("inf")
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    torch.cuda._sleep(_PROBE_CYCLES)
+                    torch.cuda.synchronize()
+                    one = min(one, (time.perf_counter() - t0) * 1e3)
+                for st in cands:
+                    if len(have) == StreamedILQR.MAX_SUB_BATCHES - 1:
+                        break
+                    if _concurrent(torch, [cur] + have + [st], one):
+                        have.append(st)
+            else:
+                have = cands[:StreamedILQR.MAX_SUB_BATCHES - 1]
+        _SIDE_STREAMS[dev.index] = have
     return have[:count]
 
 
@@ -71,13 +118,14 @@ class StreamedILQR:
         N, T, m = int(x0.shape[0]), int(nb_steps), int(u.dm_act)
         S = auto_sub_batches(u.dm_state, u.dm_act, N) if sub_batches is None else int(sub_batches)
         S = max(1, min(S, N, self.MAX_SUB_BATCHES))
+        self.device = torch.device("cuda", torch.cuda.current_device()) if kw.get("device") is None else torch.device(kw["device"])
+        self.streams = side_streams(self.device, S - 1) if S > 1 else []   # of sub-batches 1 .. S - 1
+        S = 1 + len(self.streams)
         if kff_init is None:
             kff_init = 1e-4 * np.random.randn(N, m, T)     # ilqr.py:70, one draw for the batch
         kff_init = kff_init if torch.is_tensor(kff_init) else np.asarray(kff_init, dtype=np.float64).reshape(N, m, T)
         self.nb_problems, self.nb_steps, self.sub_batches = N, T, S
         self.bounds = np.concatenate(([0], np.cumsum(split_sizes(N, S)))).tolist()
-        self.device = torch.device("cuda", torch.cuda.current_device()) if kw.get("device") is None else torch.device(kw["device"])
-        self.streams = side_streams(self.device, S - 1)   # of sub-batches 1 .. S - 1
         self._start = torch.cuda.Event()
         self._done = [torch.cuda.Event() for _ in self.streams]
         self.parts = []
