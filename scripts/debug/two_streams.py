@@ -66,6 +66,14 @@ def run_cls(env_name, N, S, seed, T=500, nb_alphas=8, K=8, W=3, max_lmbda=1e6):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+        inf = float("inf")
+        for env_name, N in (("cartpole", 65536), ("cartpole", 32768), ("cartpole", 16384), ("cartpole", 8192), ("pendulum", 65536),
+                            ("double_cartpole", 4096), ("double_cartpole", 6144), ("double_cartpole", 12288), ("double_cartpole", 32768),
+                            ("double_cartpole", 65536)):
+            for S in (1, 2, 3, 4):
+                run_cls(env_name, N - N % S, S, 2001, nb_alphas=11, K=10, W=3, max_lmbda=inf)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "c4cls":
         for seed in (100, 1337, 3001, 100, 1337):
             for S in (4, 3, 2, 1):

@@ -84,7 +84,7 @@ def test_sub_batch_rule_and_split():
     from trajopt_amd.ilqr.streamed import auto_sub_batches, split_sizes
     assert auto_sub_batches(4, 1, 4096) == 1 and auto_sub_batches(4, 1, 16384) == 1 and auto_sub_batches(4, 1, 65536) == 1
     assert auto_sub_batches(2, 1, 65536) == 1 and auto_sub_batches(2, 1, 1) == 1
-    assert auto_sub_batches(6, 1, 4096) == 1 and auto_sub_batches(6, 1, 8192) == 2 and auto_sub_batches(6, 1, 16384) == 4
+    assert auto_sub_batches(6, 1, 2048) == 1 and auto_sub_batches(6, 1, 4096) == 2 and auto_sub_batches(6, 1, 8192) == 2 and auto_sub_batches(6, 1, 16384) == 4
     assert auto_sub_batches(6, 1, 65536) == 1
     assert auto_sub_batches(12, 4, 4096) == 4 and auto_sub_batches(12, 4, 512) == 1
     for N, S in ((301, 3), (8192, 2), (7, 7), (10, 4), (1, 1)):

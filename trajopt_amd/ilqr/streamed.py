@@ -24,7 +24,7 @@ def auto_sub_batches(dm_state, dm_act, nb_problems):
     if n + m <= 5:                      # pendulum, cartpole: never (65 536 cartpoles: 6.77 -> 6.55 one day, 6.77 -> 8.18 another)
         return 1
     if n <= 6:                          # double cartpole, double pendulum: lane-per-problem backward kernels
-        if 6144 <= N < 16384:
+        if 4096 <= N < 16384:           # 4096: 1.68 -> 1.60, 6144: 2.55 -> 2.07, 12 288: 4.54 -> 3.85; 32 768: 9.8 -> 10.4
             return 2
         return 4 if 16384 <= N < 32768 else 1
     return 4 if N >= 1024 else 1        # quadrotor and larger: matrix-core backward pass with the lambda ladder
