@@ -312,7 +312,7 @@ def iteration_line(cx, env_name, N, T, alphas, K, W, seed, staged=-1, no_fusion=
         if max_lmbda == float("inf"):
             assert np.all(status == 0) and np.all(iters1 == W + K), "a problem stopped inside the timed region"
             assert np.all(np.isfinite(ret)), "non-finite trajectory cost"
-        out["streamed"] = {"sub_batches": S, "elapsed": cx.max_over_ranks(t1 - t0), "problem_iters": int((iters1 - iters0).sum()),
+        out["streamed"] = {"sub_batches": sub.sub_batches, "elapsed": cx.max_over_ranks(t1 - t0), "problem_iters": int((iters1 - iters0).sum()),
                            "gave_up": int((status == 3).sum()), "mean_return": float(ret[status == 0].mean())}
         del sub
         cx.release()

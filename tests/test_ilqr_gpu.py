@@ -686,8 +686,9 @@ def test_sub_batches_on_streams_solve_every_problem_as_the_oracle_and_as_one_bat
     one = BatchedILQR(pe, T, x0, kff_init=kff0, action_penalty=None, apply_env_kwargs=False)
     t_one = one.run(nb_iter=iters)
     sub = StreamedILQR(pe, T, x0, kff_init=kff0, sub_batches=S, action_penalty=None, apply_env_kwargs=False)
-    assert sub.sub_batches == S and len(sub.parts) == S and sub.bounds[-1] == N
-    assert sub.plan()["sub_batches"] == S
+    # (fewer than S only if the stream probe found fewer than S - 1 side streams that run next to the caller's: side_streams())
+    assert 1 <= sub.sub_batches <= S and len(sub.parts) == sub.sub_batches and sub.bounds[-1] == N
+    assert sub.plan()["sub_batches"] == sub.sub_batches
     t_sub = sub.run(nb_iter=iters)
     assert t_sub == t_one
     for k in ("xref", "uref", "K", "kff", "lmbda", "dlmbda", "status", "iters", "last_return"):
