@@ -164,7 +164,9 @@ class StreamedILQR:
 
     # -- the solver's interface --------------------------------------------------------------------------------
     def reset(self, init_state, kff_init=None, generator=None):
-        """`BatchedILQR.reset` for every sub-batch (init_state (N, dm_state), kff_init (N, dm_act, nb_steps) or None)."""
+        """`BatchedILQR.reset` for every sub-batch (init_state (N, dm_state), kff_init (N, dm_act, nb_steps) or None).
+        With a device `generator` every sub-batch draws its own block from it in turn: reproducible for a seed and a
+        sub-batch count, but not the numbers one batch would draw."""
         import torch
         N = self.nb_problems
         x0 = init_state if torch.is_tensor(init_state) else np.asarray(init_state, dtype=np.float64)
