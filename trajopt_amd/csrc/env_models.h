@@ -354,6 +354,18 @@ template <> struct Model<TRAJOPT_ENV_ROBOT> {
     }
 };
 
+// Models whose vector field does not read its first C states (the cart's position: cartpole.py:62-97,
+// double_cartpole.py:61-187 - their dx[0] is a velocity): columns
+// 0 .. C - 1 of the Jacobian of clip(RK4(x, clip(u))) are then e_c times the clip mask of xn[c] exactly - x[c] enters xn[c]
+// by one addition, every other tangent with respect to it is a sum of products with zero - and the quadratisation pushes
+// C tangent directions fewer through the dual-number arithmetic (sys.h: jacobian_cols).
+template <int MODEL> struct CyclicLeadingStates { static constexpr int value = 0; };
+template <> struct CyclicLeadingStates<TRAJOPT_ENV_CARTPOLE> { static constexpr int value = 1; };
+template <> struct CyclicLeadingStates<TRAJOPT_ENV_DOUBLE_CARTPOLE> { static constexpr int value = 1; };
+// (the quadrotor's three position states are cyclic too, but its 16 columns go in four chunks of four: the chunk that would
+// shrink to one tangent direction then carries two forms of the dual arithmetic behind a branch, and the kernel as a whole
+// got slower - 4096 quadrotors 1.91 -> 2.06 ms - so it keeps all of its columns)
+
 // robot.py:62-67 integrates with x - dt/2 k, x - dt k and xn = x - dt/6 (...): RK4 with the step -dt.  Kept as is.
 template <int MODEL> struct ReverseTime { static constexpr bool value = false; };
 template <> struct ReverseTime<TRAJOPT_ENV_ROBOT> { static constexpr bool value = true; };

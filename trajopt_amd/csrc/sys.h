@@ -29,6 +29,37 @@ struct SysPhys {
     template <int KC>
     static __device__ __forceinline__ void jacobian_cols(const trajopt_env_t& e, const double (&x)[N],
                                                          const double (&u)[M], int k0, double (&J)[N][KC]) {
+        constexpr int C = CyclicLeadingStates<MODEL>::value;
+        if constexpr (C > 0 && C < KC) {
+            // the chunk that holds the cyclic states' columns (k0 = 0; with all columns in one chunk the only one): KC - C
+            // tangent directions, columns 0 .. C - 1 written down
+            if (KC == N + M || k0 == 0) {
+                constexpr int K1 = KC - C;
+                Dual<K1> xd[N], ud[M], xn[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    xd[i] = constant<K1>(x[i]);
+#pragma unroll
+                    for (int k = 0; k < K1; ++k) xd[i].d[k] = (i == k + C) ? 1.0 : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    ud[j] = constant<K1>(u[j]);
+#pragma unroll
+                    for (int k = 0; k < K1; ++k) ud[j].d[k] = (N + j == k + C) ? 1.0 : 0.0;
+                }
+                env_dynamics<MODEL, Dual<K1>>(e, xd, ud, xn);
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)   // clip_g's mask
+                        J[i][c] = (i == c && xn[c].v != -e.xmax[c] && xn[c].v != e.xmax[c]) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < K1; ++k) J[i][k + C] = xn[i].d[k];
+                }
+                return;
+            }
+        }
         Dual<KC> xd[N], ud[M], xn[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
