@@ -709,3 +709,36 @@ def test_sub_batches_on_streams_solve_every_problem_as_the_oracle_and_as_one_bat
     one.iterate(iters)
     for k in ("xref", "uref", "last_return", "iters", "status"):
         assert np.array_equal(sub.host(k), one.host(k)), k
+
+
+def test_sub_batches_draw_their_noise_and_hand_out_device_vectors():
+    """StreamedILQR's remaining entry points: kff_init = None draws ONE (N, m, T) block for the batch (ilqr.py:70) and deals
+    it out; reset(generator=...) draws per sub-batch on the device, reproducibly; vector() is the (N,) device tensor in
+    problem order."""
+    import torch
+    from trajopt_amd import envs
+    from trajopt_amd.ilqr import StreamedILQR
+    N, T = 50, 16
+    env = envs.make("cartpole", dt=0.02)
+    rng = np.random.Generator(np.random.PCG64(9))
+    x0 = np.array([0., np.pi, 0., 0.])[None] + 1e-2 * rng.standard_normal((N, 4))
+    np.random.seed(123)
+    want = 1e-4 * np.random.randn(N, 1, T)
+    np.random.seed(123)
+    s = StreamedILQR(env, T, x0, sub_batches=3, action_penalty=1e-5)
+    assert np.array_equal(s.host("kff"), want)
+    s.run(nb_iter=2)
+    v = s.vector("last_return")
+    assert v.is_cuda and v.shape == (N,) and np.array_equal(v.cpu().numpy(), s.host("last_return"))
+    assert np.array_equal(s.vector("iters").cpu().numpy(), s.host("iters"))
+    draws = []
+    for seed in (4, 4, 5):
+        g = torch.Generator(device=s.device)
+        g.manual_seed(seed)
+        s.reset(x0, generator=g)
+        draws.append(s.host("kff").copy())
+    assert np.array_equal(draws[0], draws[1]) and not np.array_equal(draws[0], draws[2])
+    assert abs(draws[0].std() / 1e-4 - 1.0) < 0.15
+    # the blocks of different sub-batches are different draws
+    b = s.bounds
+    assert not np.array_equal(draws[0][b[0]:b[0] + 10], draws[0][b[1]:b[1] + 10])
