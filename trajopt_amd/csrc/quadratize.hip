@@ -47,123 +47,158 @@ __global__ __launch_bounds__(64) void quadratize_kernel(QuadArgs a) {
     // grid = (problem blocks, T + 1, tangent chunks): no 64-bit division in the index math
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int t = (int)blockIdx.y, chunk = (int)blockIdx.z;
-    if (p >= NP) return;
+    // Lanes without a problem (p >= NP, or one the driver has stopped) compute nothing - but where a wave's chunk goes out
+    // through the LDS stage (kStage, below) they still help to write their neighbours' columns.
+    const bool live = p < NP && !(a.active && a.active[p < NP ? p : 0] == 0);
     const size_t En1 = (size_t)n * (T + 1), Em = (size_t)m * T;
-    if (a.active && a.active[p] == 0) return;
-
-    double x[N], u[M], ul[M];
-    bool through = false;
-    const int k = a.ref_plane ? a.ref_plane[p] : -1;
-    if (k >= 0) {   // the driver: time-blocked candidate plane ref_plane[p] (common.h)
-        const double* xs = a.cand_state + (size_t)k * tb_plane(n, T + 1, NP);
-        const double* us = a.cand_action + (size_t)k * tb_plane(m, T, NP);
+    typedef double q_v2 __attribute__((ext_vector_type(2)));
+    // kStage (PROBLEM_MAJOR outputs, static even dx, chunks that do not straddle A | B: quadrotor, quad pendulum): a lane's
+    // chunk is ONE contiguous run of KC * dx doubles of its (problem, step) - written straight from the lanes every 16-byte
+    // store of the wave lands in 64 different cache lines, and the kernel is bound by exactly that.
+    // So the wave's 64 runs go through LDS and out again with consecutive lanes on consecutive 16-byte pieces: whole lines.
+    constexpr bool kStage = !OMINOR && SYS::kStatic && N % 2 == 0 && N % KC == 0 && (N + M) % KC == 0;
+    constexpr int kPieces = KC * N / 2;   // 16-byte pieces of a lane's run
+    __shared__ q_v2 s_stage[kStage ? 64 * kPieces : 1];
+    bool staged = false;
+    if (live) {
+        double x[N], u[M], ul[M];
+        bool through = false;
+        const int k = a.ref_plane ? a.ref_plane[p] : -1;
+        if (k >= 0) {   // the driver: time-blocked candidate plane ref_plane[p] (common.h)
+            const double* xs = a.cand_state + (size_t)k * tb_plane(n, T + 1, NP);
+            const double* us = a.cand_action + (size_t)k * tb_plane(m, T, NP);
 #pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = (i < n) ? xs[tb_index(n, t, i, p, NP)] : 0.0;
+            for (int i = 0; i < N; ++i) x[i] = (i < n) ? xs[tb_index(n, t, i, p, NP)] : 0.0;
 #pragma unroll
-        for (int j = 0; j < M; ++j) {
-            u[j] = (j < m && t < T) ? us[tb_index(m, t, j, p, NP)] : 0.0;
-            ul[j] = (j < m && t >= 1) ? us[tb_index(m, t - 1, j, p, NP)] : 0.0;
-        }
-        through = (chunk == 0 && a.uref_out != nullptr && a.xref_out != nullptr);
-    } else {
+            for (int j = 0; j < M; ++j) {
+                u[j] = (j < m && t < T) ? us[tb_index(m, t, j, p, NP)] : 0.0;
+                ul[j] = (j < m && t >= 1) ? us[tb_index(m, t - 1, j, p, NP)] : 0.0;
+            }
+            through = (chunk == 0 && a.uref_out != nullptr && a.xref_out != nullptr);
+        } else {
 #pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = (i < n) ? a.xref[qi<MINOR>((size_t)n * t + i, En1, p, NP)] : 0.0;
+            for (int i = 0; i < N; ++i) x[i] = (i < n) ? a.xref[qi<MINOR>((size_t)n * t + i, En1, p, NP)] : 0.0;
 #pragma unroll
-        for (int j = 0; j < M; ++j) {
-            // _u = hstack(u, 0): the pad is u_T and, through Python's negative index, also u_last at t = 0
-            u[j] = (j < m && t < T) ? a.uref[qi<MINOR>((size_t)m * t + j, Em, p, NP)] : 0.0;
-            ul[j] = (j < m && t >= 1) ? a.uref[qi<MINOR>((size_t)m * (t - 1) + j, Em, p, NP)] : 0.0;
-        }
-    }
-    if (through) {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            if (i < n) a.xref_out[qi<MINOR>((size_t)n * t + i, En1, p, NP)] = x[i];
-#pragma unroll
-        for (int j = 0; j < M; ++j)
-            if (j < m && t < T) a.uref_out[qi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
-    }
-
-    if (t < T) {  // dynamics Jacobian columns of this chunk
-        const int k0 = chunk * KC;
-        double J[N][KC];
-        SYS::template jacobian_cols<KC>(e, x, u, k0, J);
-        const size_t Enn = (size_t)n * n * T, Enm = (size_t)n * m * T;
-        // PROBLEM_MAJOR outputs with an even, static dx (quadrotor): a column of a step is dx consecutive doubles at a
-        // 16-byte aligned address - written two rows a store (half as many store instructions, each of which touches
-        // 64 different cache lines whatever its width)
-        typedef double q_v2 __attribute__((ext_vector_type(2)));
-        constexpr bool kPair = !OMINOR && SYS::kStatic && N % 2 == 0;
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            const int col = k0 + k;
-            if (col < n) {
-                double* dst = a.A + qi<OMINOR>((size_t)n * n * t + (size_t)n * col, Enn, p, NP);
-                if constexpr (kPair) {
-#pragma unroll
-                    for (int i = 0; i < N; i += 2) *reinterpret_cast<q_v2*>(dst + i) = q_v2{J[i][k], J[i + 1][k]};
-                } else {
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        if (i < n) a.A[qi<OMINOR>((size_t)n * n * t + i + (size_t)n * col, Enn, p, NP)] = J[i][k];
-                }
-            } else if (col < n + m) {
-                double* dst = a.B + qi<OMINOR>((size_t)n * m * t + (size_t)n * (col - n), Enm, p, NP);
-                if constexpr (kPair) {
-#pragma unroll
-                    for (int i = 0; i < N; i += 2) *reinterpret_cast<q_v2*>(dst + i) = q_v2{J[i][k], J[i + 1][k]};
-                } else {
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        if (i < n) a.B[qi<OMINOR>((size_t)n * m * t + i + (size_t)n * (col - n), Enm, p, NP)] = J[i][k];
-                }
+            for (int j = 0; j < M; ++j) {
+                // _u = hstack(u, 0): the pad is u_T and, through Python's negative index, also u_last at t = 0
+                u[j] = (j < m && t < T) ? a.uref[qi<MINOR>((size_t)m * t + j, Em, p, NP)] : 0.0;
+                ul[j] = (j < m && t >= 1) ? a.uref[qi<MINOR>((size_t)m * (t - 1) + j, Em, p, NP)] : 0.0;
             }
         }
-    }
-    if (chunk == 0) {  // cost expansion (objects.py:72-78)
-        const double w = a.weighting[t];
-        const double sc = e.cost_times_dt ? e.dt : 1.0;
-        const size_t Enn1 = (size_t)n * n * (T + 1), Emm1 = (size_t)m * m * (T + 1), Enm1 = (size_t)n * m * (T + 1),
-                     Em1 = (size_t)m * (T + 1);
-        double fgx[N], fhxx[N];
-        if (e.nb_features != 0) feature_cost<N, true>(e, x, n, fgx, fhxx);
+        if (through) {
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-            if (i < n) {
-                double g = 0.0, h = 0.0;
-                if (w != 0.0) {
-                    if (e.nb_features == 0) {
-                        const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
-                        h = w * (sc * 2.0 * e.gw[i]);  // = w[t] * cost_gxx[i], the structured form the backward pass can take
-                        g = h * (y - e.goal[i]);
-                    } else {   // frozen feature Jacobian (cartpole.py:122-124): Gauss-Newton
-                        h = w * (sc * 2.0) * fhxx[i];
-                        g = w * (sc * 2.0) * fgx[i];
+            for (int i = 0; i < N; ++i)
+                if (i < n) a.xref_out[qi<MINOR>((size_t)n * t + i, En1, p, NP)] = x[i];
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if (j < m && t < T) a.uref_out[qi<MINOR>((size_t)m * t + j, Em, p, NP)] = u[j];
+        }
+
+        if (t < T) {  // dynamics Jacobian columns of this chunk
+            const int k0 = chunk * KC;
+            double J[N][KC];
+            SYS::template jacobian_cols<KC>(e, x, u, k0, J);
+            const size_t Enn = (size_t)n * n * T, Enm = (size_t)n * m * T;
+            // PROBLEM_MAJOR outputs with an even, static dx (quadrotor): a column of a step is dx consecutive doubles at a
+            // 16-byte aligned address - written two rows a store (half as many store instructions, each of which touches
+            // 64 different cache lines whatever its width)
+            constexpr bool kPair = !OMINOR && SYS::kStatic && N % 2 == 0;
+            if constexpr (kStage) {
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+#pragma unroll
+                    for (int i = 0; i < N; i += 2)
+                        s_stage[(int)threadIdx.x * kPieces + k * (N / 2) + i / 2] = q_v2{J[i][k], J[i + 1][k]};
+                staged = true;
+            } else
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int col = k0 + k;
+                if (col < n) {
+                    double* dst = a.A + qi<OMINOR>((size_t)n * n * t + (size_t)n * col, Enn, p, NP);
+                    if constexpr (kPair) {
+#pragma unroll
+                        for (int i = 0; i < N; i += 2) *reinterpret_cast<q_v2*>(dst + i) = q_v2{J[i][k], J[i + 1][k]};
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < N; ++i)
+                            if (i < n) a.A[qi<OMINOR>((size_t)n * n * t + i + (size_t)n * col, Enn, p, NP)] = J[i][k];
+                    }
+                } else if (col < n + m) {
+                    double* dst = a.B + qi<OMINOR>((size_t)n * m * t + (size_t)n * (col - n), Enm, p, NP);
+                    if constexpr (kPair) {
+#pragma unroll
+                        for (int i = 0; i < N; i += 2) *reinterpret_cast<q_v2*>(dst + i) = q_v2{J[i][k], J[i + 1][k]};
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < N; ++i)
+                            if (i < n) a.B[qi<OMINOR>((size_t)n * m * t + i + (size_t)n * (col - n), Enm, p, NP)] = J[i][k];
                     }
                 }
-                a.cx[qi<OMINOR>((size_t)n * t + i, En1, p, NP)] = g;
-                if (a.Cxx) {  // NULL: the backward pass forms Cxx, Cuu, Cxu itself (trajopt_backward_io_t::cost_w)
-#pragma unroll
-                    for (int j = 0; j < N; ++j)
-                        if (j < n) a.Cxx[qi<OMINOR>((size_t)n * n * t + j + (size_t)n * i, Enn1, p, NP)] = (i == j) ? h : 0.0;
-#pragma unroll
-                    for (int j = 0; j < M; ++j)
-                        if (j < m) a.Cxu[qi<OMINOR>((size_t)n * m * t + i + (size_t)n * j, Enm1, p, NP)] = 0.0;
-                }
             }
+        }
+        if (chunk == 0) {  // cost expansion (objects.py:72-78)
+            const double w = a.weighting[t];
+            const double sc = e.cost_times_dt ? e.dt : 1.0;
+            const size_t Enn1 = (size_t)n * n * (T + 1), Emm1 = (size_t)m * m * (T + 1), Enm1 = (size_t)n * m * (T + 1),
+                         Em1 = (size_t)m * (T + 1);
+            double fgx[N], fhxx[N];
+            if (e.nb_features != 0) feature_cost<N, true>(e, x, n, fgx, fhxx);
 #pragma unroll
-        for (int j = 0; j < M; ++j)
-            if (j < m) {
-                const double d = e.slew_rate ? (u[j] - ul[j]) : u[j];
-                a.cu[qi<OMINOR>((size_t)m * t + j, Em1, p, NP)] = sc * 2.0 * e.uw[j] * d;
-                if (a.Cxx) {
+            for (int i = 0; i < N; ++i)
+                if (i < n) {
+                    double g = 0.0, h = 0.0;
+                    if (w != 0.0) {
+                        if (e.nb_features == 0) {
+                            const double y = ((e.periodic >> i) & 1) ? wrap_angle(x[i]) : x[i];
+                            h = w * (sc * 2.0 * e.gw[i]);  // = w[t] * cost_gxx[i], the structured form the backward pass can take
+                            g = h * (y - e.goal[i]);
+                        } else {   // frozen feature Jacobian (cartpole.py:122-124): Gauss-Newton
+                            h = w * (sc * 2.0) * fhxx[i];
+                            g = w * (sc * 2.0) * fgx[i];
+                        }
+                    }
+                    a.cx[qi<OMINOR>((size_t)n * t + i, En1, p, NP)] = g;
+                    if (a.Cxx) {  // NULL: the backward pass forms Cxx, Cuu, Cxu itself (trajopt_backward_io_t::cost_w)
 #pragma unroll
-                    for (int k = 0; k < M; ++k)
-                        if (k < m)
-                            a.Cuu[qi<OMINOR>((size_t)m * m * t + k + (size_t)m * j, Emm1, p, NP)] =
-                                (k == j) ? sc * 2.0 * e.uw[j] : 0.0;
+                        for (int j = 0; j < N; ++j)
+                            if (j < n) a.Cxx[qi<OMINOR>((size_t)n * n * t + j + (size_t)n * i, Enn1, p, NP)] = (i == j) ? h : 0.0;
+#pragma unroll
+                        for (int j = 0; j < M; ++j)
+                            if (j < m) a.Cxu[qi<OMINOR>((size_t)n * m * t + i + (size_t)n * j, Enm1, p, NP)] = 0.0;
+                    }
                 }
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if (j < m) {
+                    const double d = e.slew_rate ? (u[j] - ul[j]) : u[j];
+                    a.cu[qi<OMINOR>((size_t)m * t + j, Em1, p, NP)] = sc * 2.0 * e.uw[j] * d;
+                    if (a.Cxx) {
+#pragma unroll
+                        for (int k = 0; k < M; ++k)
+                            if (k < m)
+                                a.Cuu[qi<OMINOR>((size_t)m * m * t + k + (size_t)m * j, Emm1, p, NP)] =
+                                    (k == j) ? sc * 2.0 * e.uw[j] : 0.0;
+                    }
+                }
+        }
+    }
+    if constexpr (kStage) {
+        if (t < T) {   // (uniform: one step a block)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long okm = __ballot(staged);
+            const int k0 = chunk * KC, lane = (int)threadIdx.x;
+            const size_t p0 = (size_t)blockIdx.x * 64;
+            const bool isA = k0 < n;
+            const size_t E = isA ? (size_t)n * n * T : (size_t)n * m * T;
+            double* base = isA ? a.A + (size_t)n * n * t + (size_t)n * k0 : a.B + (size_t)n * m * t + (size_t)n * (k0 - n);
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) {
+                const int g = i * 64 + lane, src = g / kPieces, piece = g % kPieces;   // the lane that computed it, piece of its run
+                if ((okm >> src) & 1ull) *reinterpret_cast<q_v2*>(base + (p0 + (size_t)src) * E + 2 * piece) = s_stage[g];
             }
+        }
     }
 }
 
