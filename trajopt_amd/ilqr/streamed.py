@@ -6,7 +6,7 @@ chain of launches of which several do not fill the chip: the backward pass of th
 problems that climb the lambda ladder, the rollout of 8192 double cartpoles leaves a third of the SIMDs with one wave.
 Two to four sub-batches on streams of their own run those launches side by side - one sub-batch's rollout under
 another's backward pass.  Measured on MI355X (ms per iteration, one batch -> sub-batches; scripts/debug/two_streams.py):
-4096 quadrotors 7.5 -> 6.2 (4; never giving up 19.8 -> 15.3), 8192 double cartpoles 2.97 -> 2.65 (2), 16 384 double
+4096 quadrotors 7.35 -> 5.97 (4; never giving up 19.4 -> 14.9), 8192 double cartpoles 2.97 -> 2.67 (2), 16 384 double
 cartpoles 5.62 -> 5.19 (4); 4096 and 16 384 cartpoles lose (0.66 -> 0.76, 2.10 -> 2.35: their launches are a lone wave's
 chain each, which a second stream only delays) and 65 536 gain nothing reliable, so the small models stay one batch.
 
